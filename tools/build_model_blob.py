@@ -1,0 +1,39 @@
+"""Compile the reference's fruit-fly MJCF into the committed model blob.
+
+Runs only where `/root/reference` exists (this container); the GPU box uses the committed
+`flybody_amd/assets/fly_flight.ffmb` + `fly_flight.json`.
+
+    python tools/build_model_blob.py
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+from flybody_amd.model.blob import model_tensors, write_blob
+from flybody_amd.model.compiler import build_flight_model
+
+OUT = os.path.join(os.path.dirname(__file__), "..", "flybody_amd", "assets")
+
+
+def main():
+    m, L = build_flight_model()
+    write_blob(os.path.join(OUT, "fly_flight.ffmb"), model_tensors(m, L))
+    meta = {
+        "body_name": m.body_name,
+        "jnt_name": m.jnt_name,
+        "act_name": m.act_name,
+        "ten_name": m.ten_name,
+        "observable_joints": m.walker["observable_joints"],
+        "action_names": [m.act_name[i] for c in ("adhesion", "head", "mouth", "antennae", "wings", "abdomen", "legs")
+                         for i in (m.walker["ctrl_indices"][c] or [])] + ["user_0"],
+        "notes": {k: (float(v) if not isinstance(v, (list, str)) else v) for k, v in m.notes.items()},
+    }
+    with open(os.path.join(OUT, "fly_flight.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", OUT, "nbody", m.nbody, "nv", m.nv, "nu", m.nu)
+
+
+if __name__ == "__main__":
+    main()
