@@ -1,0 +1,260 @@
+"""ctypes front-end for the float64 CPU oracle (`fly_oracle.c`).
+
+TEST INFRASTRUCTURE ONLY - see the header of `fly_oracle.c`.  Imported by tests/, by
+`__graft_entry__.smoke()` and by `bench.py`'s cpu_baseline leg; never by `flybody_amd/`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "_build", "libfly_oracle.so")
+
+FO_NO_FLUID, FO_NO_LIMIT, FO_NO_DAMPER, FO_NO_SPRING, FO_NO_GRAVITY, FO_NO_ACTUATION = 1, 2, 4, 8, 16, 32
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_DIR, "fly_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _DIR, "-s"] + (["-B"] if force else []))
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.fo_model_load.restype = vp
+        L.fo_model_load.argtypes = [C.c_char_p]
+        L.fo_data_new.restype = vp
+        L.fo_data_new.argtypes = [vp]
+        for n in ("fo_nq", "fo_nv", "fo_nu", "fo_nbody", "fo_njnt", "fo_nM", "fo_naction"):
+            getattr(L, n).restype = C.c_int
+            getattr(L, n).argtypes = [vp]
+        for n in ("fo_qpos", "fo_qvel", "fo_ctrl", "fo_qacc", "fo_qacc_smooth", "fo_qfrc_bias", "fo_qfrc_passive",
+                  "fo_qfrc_actuator", "fo_qfrc_constraint", "fo_xpos", "fo_xquat", "fo_xipos", "fo_subtree_com",
+                  "fo_cvel", "fo_sensors", "fo_time"):
+            getattr(L, n).restype = dp
+            getattr(L, n).argtypes = [vp]
+        L.fo_nefc.restype = C.c_int
+        L.fo_nefc.argtypes = [vp]
+        L.fo_solver_iter.restype = C.c_int
+        L.fo_solver_iter.argtypes = [vp]
+        L.fo_set_flags.argtypes = [vp, C.c_int]
+        L.fo_set_timestep.argtypes = [vp, C.c_double]
+        L.fo_get_timestep.restype = C.c_double
+        L.fo_get_timestep.argtypes = [vp]
+        L.fo_step1.argtypes = [vp, vp]
+        L.fo_step2.argtypes = [vp, vp]
+        L.fo_step.argtypes = [vp, vp]
+        L.fo_forward.argtypes = [vp, vp, C.c_int]
+        L.fo_dense_M.argtypes = [vp, vp, dp]
+        L.fo_energy.restype = C.c_double
+        L.fo_energy.argtypes = [vp, vp, dp, dp]
+        L.fo_momentum.argtypes = [vp, vp, dp, dp]
+        L.fo_rng.restype = C.c_uint64
+        L.fo_rng.argtypes = [C.c_uint64] * 4
+        L.fo_u01.restype = C.c_double
+        L.fo_u01.argtypes = [C.c_uint64]
+        L.fo_env_new.restype = vp
+        L.fo_env_new.argtypes = [vp, C.c_int, dp, ip, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64]
+        L.fo_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
+        L.fo_env_force_next.argtypes = [vp, C.c_int, C.c_double]
+        L.fo_env_set_pad_first_obs.argtypes = [vp, C.c_int]
+        L.fo_env_data.restype = vp
+        L.fo_env_data.argtypes = [vp]
+        L.fo_env_ghost.argtypes = [vp, dp]
+        L.fo_env_wbpg_state.argtypes = [vp, ip, ip, dp]
+        L.fo_env_wbpg_reset.argtypes = [vp, C.c_double, dp, dp]
+        L.fo_env_wbpg_step.argtypes = [vp, C.c_double, dp]
+        L.fo_test_quat.argtypes = [C.c_int, dp, dp, dp]
+        L.fo_env_counters.restype = C.c_int
+        L.fo_env_counters.argtypes = [vp, ip, ip]
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class OracleModel:
+    def __init__(self, blob_path: str):
+        self.L = lib()
+        self.ptr = self.L.fo_model_load(blob_path.encode())
+        if not self.ptr:
+            raise RuntimeError(f"cannot load {blob_path}")
+        for n in ("nq", "nv", "nu", "nbody", "njnt", "nM", "naction"):
+            setattr(self, n, getattr(self.L, "fo_" + n)(self.ptr))
+
+    def set_flags(self, flags: int):
+        self.L.fo_set_flags(self.ptr, flags)
+
+    @property
+    def timestep(self):
+        return self.L.fo_get_timestep(self.ptr)
+
+    @timestep.setter
+    def timestep(self, h):
+        self.L.fo_set_timestep(self.ptr, float(h))
+
+
+class OracleData:
+    """numpy views straight onto the C arrays."""
+
+    def __init__(self, model: OracleModel, ptr=None):
+        self.m, self.L = model, model.L
+        self.ptr = ptr if ptr is not None else self.L.fo_data_new(model.ptr)
+        m = model
+
+        def view(name, n):
+            return np.ctypeslib.as_array(getattr(self.L, name)(self.ptr), shape=(n,))
+
+        self.qpos, self.qvel, self.ctrl = view("fo_qpos", m.nq), view("fo_qvel", m.nv), view("fo_ctrl", m.nu)
+        self.qacc, self.qacc_smooth = view("fo_qacc", m.nv), view("fo_qacc_smooth", m.nv)
+        self.qfrc_bias, self.qfrc_passive = view("fo_qfrc_bias", m.nv), view("fo_qfrc_passive", m.nv)
+        self.qfrc_actuator, self.qfrc_constraint = view("fo_qfrc_actuator", m.nv), view("fo_qfrc_constraint", m.nv)
+        self.xpos = view("fo_xpos", 3 * m.nbody).reshape(-1, 3)
+        self.xquat = view("fo_xquat", 4 * m.nbody).reshape(-1, 4)
+        self.xipos = view("fo_xipos", 3 * m.nbody).reshape(-1, 3)
+        self.subtree_com = view("fo_subtree_com", 3 * m.nbody).reshape(-1, 3)
+        self.cvel = view("fo_cvel", 6 * m.nbody).reshape(-1, 6)
+        self.sensors = view("fo_sensors", 9)  # gyro, velocimeter, accelerometer
+        self._time = view("fo_time", 1)
+
+    @property
+    def time(self):
+        return float(self._time[0])
+
+    @property
+    def nefc(self):
+        return self.L.fo_nefc(self.ptr)
+
+    @property
+    def solver_iter(self):
+        return self.L.fo_solver_iter(self.ptr)
+
+    def step1(self):
+        self.L.fo_step1(self.m.ptr, self.ptr)
+
+    def step2(self):
+        self.L.fo_step2(self.m.ptr, self.ptr)
+
+    def step(self):
+        self.L.fo_step(self.m.ptr, self.ptr)
+
+    def forward(self, skip_actuation=False):
+        self.L.fo_forward(self.m.ptr, self.ptr, int(skip_actuation))
+
+    def dense_M(self):
+        out = np.zeros((self.m.nv, self.m.nv))
+        self.L.fo_dense_M(self.m.ptr, self.ptr, _dp(out))
+        return out
+
+    def energy(self):
+        k, p = C.c_double(), C.c_double()
+        e = self.L.fo_energy(self.m.ptr, self.ptr, C.byref(k), C.byref(p))
+        return e, k.value, p.value
+
+    def momentum(self):
+        lin, ang = np.zeros(3), np.zeros(3)
+        self.L.fo_momentum(self.m.ptr, self.ptr, _dp(lin), _dp(ang))
+        return lin, ang
+
+
+class OracleFlightEnv:
+    """Single-instance float64 flight-imitation env (dm_env semantics, one call = one control step).
+
+    `wbpg` is a `flybody_amd.tasks.wbpg.WingBeatTables`-like object (attributes beat_freqs, tab_off, traj,
+    phase, base_freq, rel_range, rate, dt_ctrl); `refs` holds preprocessed `ref_qpos (N,T,7)` root poses
+    and `ref_qvel (N,T,6)`."""
+
+    OBS = 104
+
+    def __init__(self, model: OracleModel, wbpg, ref_qpos, ref_qvel, *, future_steps=5, time_limit_steps=3000,
+                 terminal_com_dist=2.0, ghost_accel_z=0.0, seed=0, env_id=0):
+        self.model, self.L = model, model.L
+        self._keep = dict(
+            bf=np.ascontiguousarray(wbpg.beat_freqs, dtype=np.float64),
+            off=np.ascontiguousarray(wbpg.tab_off, dtype=np.int32),
+            traj=np.ascontiguousarray(wbpg.traj, dtype=np.float64),
+            phase=np.ascontiguousarray(wbpg.phase, dtype=np.float64),
+            rq=np.ascontiguousarray(ref_qpos, dtype=np.float64),
+            rv=np.ascontiguousarray(ref_qvel, dtype=np.float64),
+        )
+        k = self._keep
+        n, t = k["rq"].shape[:2]
+        self.ptr = self.L.fo_env_new(model.ptr, len(k["bf"]), _dp(k["bf"]), _ip(k["off"]), _dp(k["traj"]), _dp(k["phase"]),
+                                     float(wbpg.base_freq), float(wbpg.rel_range), float(wbpg.rate), float(wbpg.dt_ctrl),
+                                     n, t, _dp(k["rq"]), _dp(k["rv"]), future_steps, time_limit_steps,
+                                     float(terminal_com_dist), float(ghost_accel_z), seed, env_id)
+        self.data = OracleData(model, self.L.fo_env_data(self.ptr))
+        self.naction = model.naction
+
+    def force_next(self, traj_idx: int, phase: float):
+        self.L.fo_env_force_next(self.ptr, int(traj_idx), float(phase))
+
+    def set_pad_first_obs(self, v: bool):
+        self.L.fo_env_set_pad_first_obs(self.ptr, int(v))
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        obs = np.zeros(self.OBS)
+        r, dsc, st = C.c_double(), C.c_double(), C.c_int()
+        self.L.fo_env_step(self.ptr, _dp(a), _dp(obs), C.byref(r), C.byref(dsc), C.byref(st))
+        return st.value, r.value, dsc.value, obs
+
+    def ghost(self):
+        g = np.zeros(7)
+        self.L.fo_env_ghost(self.ptr, _dp(g))
+        return g
+
+    def wbpg_state(self):
+        s, f, c = C.c_int(), C.c_int(), C.c_double()
+        self.L.fo_env_wbpg_state(self.ptr, C.byref(s), C.byref(f), C.byref(c))
+        return s.value, f.value, c.value
+
+    def wbpg_reset(self, phase):
+        q, v = np.zeros(6), np.zeros(6)
+        self.L.fo_env_wbpg_reset(self.ptr, float(phase), _dp(q), _dp(v))
+        return q, v
+
+    def wbpg_step(self, ctrl_freq):
+        q = np.zeros(6)
+        self.L.fo_env_wbpg_step(self.ptr, float(ctrl_freq), _dp(q))
+        return q
+
+    def counters(self):
+        t, s = C.c_int(), C.c_int()
+        nr = self.L.fo_env_counters(self.ptr, C.byref(t), C.byref(s))
+        return t.value, s.value, bool(nr)
+
+
+def rng_u64(seed, env, episode, stream):
+    return int(lib().fo_rng(seed, env, episode, stream))
+
+
+def rng_u01(seed, env, episode, stream):
+    return float(lib().fo_u01(lib().fo_rng(seed, env, episode, stream)))
+
+
+def test_quat(op: int, a, b=None, nout=4):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.zeros(4) if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros(nout)
+    lib().fo_test_quat(op, _dp(a), _dp(b), _dp(out))
+    return out

@@ -1,0 +1,179 @@
+"""Known-answer checks that pin the float64 physics oracle in lieu of a runnable MuJoCo
+(SURVEY.md section 8c (v)-(vi))."""
+import numpy as np
+import pytest
+
+from conftest import BLOB, HAVE_REFERENCE
+from oracle import oracle as O
+
+
+@pytest.fixture()
+def md():
+    m = O.OracleModel(BLOB)
+    return m, O.OracleData(m)
+
+
+def _excite(m, d, seed=1, amp=20.0):
+    rng = np.random.RandomState(seed)
+    q0 = d.qpos.copy()
+    d.qpos[7:] = q0[7:] + rng.uniform(-0.1, 0.1, m.nq - 7)
+    d.qpos[:3] = [0, 0, 1.0]
+    d.qvel[:] = 0
+    d.qvel[:3] = [10, 5, -3]
+    d.qvel[3:6] = [20, -10, 5]
+    d.qvel[6:] = rng.randn(m.nv - 6) * amp
+
+
+def test_mass_matrix_symmetric_pd(md):
+    m, d = md
+    _excite(m, d)
+    d.forward()
+    M = d.dense_M()
+    assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="compiles the model from the reference assets")
+def test_mass_matrix_matches_independent_numpy_crb(md):
+    from flybody_amd.model import pyref
+    from flybody_amd.model.compiler import build_flight_model
+
+    m, d = md
+    mc, _ = build_flight_model()
+    _excite(m, d)
+    q = d.qpos.copy()
+    d.forward()
+    assert np.abs(d.dense_M() - pyref.mass_matrix(mc, q)).max() < 1e-18
+
+
+def test_gravity_bias_is_potential_gradient(md):
+    m, d = md
+    _excite(m, d)
+    q = d.qpos.copy()
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_DAMPER | O.FO_NO_SPRING)
+    d.qvel[:] = 0
+    d.forward()
+    bias = d.qfrc_bias.copy()
+
+    def pot(qq):
+        d.qpos[:] = qq
+        d.forward()
+        return d.energy()[2]
+
+    eps = 1e-6
+    for qi, vi in [(0, 0), (2, 2)] + [(i, i - 1) for i in range(7, m.nq)]:
+        qp, qm = q.copy(), q.copy()
+        qp[qi] += eps
+        qm[qi] -= eps
+        assert abs((pot(qp) - pot(qm)) / (2 * eps) - bias[vi]) < 1e-8
+
+
+@pytest.mark.parametrize("quantity", ["energy", "momentum"])
+def test_invariants_converge_first_order(md, quantity):
+    """Semi-implicit Euler: the drift of a conserved quantity over a fixed horizon halves with h."""
+    m, d = md
+    errs = []
+    for h in (5e-5, 2.5e-5):
+        m.timestep = h
+        n = int(round(0.02 / h))
+        if quantity == "energy":
+            m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_DAMPER | O.FO_NO_ACTUATION)
+        else:
+            m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_GRAVITY | O.FO_NO_ACTUATION)
+        d2 = O.OracleData(m)
+        _excite(m, d2)
+        d2.forward()
+        e0, (l0, a0) = d2.energy()[0], d2.momentum()
+        for _ in range(n):
+            d2.step()
+        d2.forward()
+        if quantity == "energy":
+            errs.append(abs(d2.energy()[0] - e0) / abs(e0))
+        else:
+            l1, a1 = d2.momentum()
+            errs.append(max(np.abs(l1 - l0).max() / np.abs(l0).max(), np.abs(a1 - a0).max() / np.abs(a0).max()))
+    assert errs[0] < 1e-3 and 1.7 < errs[0] / errs[1] < 2.3
+
+
+def test_free_fall_reads_zero_proper_acceleration(md):
+    m, d = md
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_ACTUATION | O.FO_NO_SPRING)
+    d.qvel[:] = 0
+    d.forward()
+    assert np.abs(d.sensors[6:9]).max() < 1e-9  # accelerometer
+    np.testing.assert_allclose(d.qacc[:3], [0, 0, -981.0], atol=1e-9)
+    assert np.abs(d.qacc[3:]).max() < 1e-8
+
+
+def test_accelerometer_of_held_fly_reads_g_along_world_z(md):
+    """A fly whose root acceleration is exactly cancelled reads +981 along world-z in the thorax frame."""
+    m, d = md
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_ACTUATION | O.FO_NO_SPRING | O.FO_NO_GRAVITY)
+    th = np.deg2rad(47.5)
+    d.qpos[3:7] = [np.cos(th / 2), 0, -np.sin(th / 2), 0]
+    d.qvel[:] = 0
+    d.forward()
+    assert np.abs(d.sensors[6:9]).max() < 1e-9
+    # world acceleration +g of the frame is equivalent to gravity on with the fly held: use the relation
+    # accelerometer = R^T (a - g) with a = 0  ->  R^T [0,0,981]
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_ACTUATION | O.FO_NO_SPRING)
+    d.forward()
+    # subtract the free-fall acceleration the fly actually has (qacc root = -981 z, measured above)
+    R = np.array([[np.cos(th), 0, -np.sin(th)], [0, 1, 0], [np.sin(th), 0, np.cos(th)]])
+    held = d.sensors[6:9] + R.T @ np.array([0, 0, 981.0])
+    np.testing.assert_allclose(held, R.T @ np.array([0, 0, 981.0]), atol=1e-9)
+
+
+def test_terminal_velocity_inertia_box_drag(md):
+    """A non-rotating fly falling flat reaches the speed where the summed box drag equals its weight."""
+    m, d = md
+    m.set_flags(O.FO_NO_LIMIT | O.FO_NO_ACTUATION)
+    d.qvel[:] = 0
+    v_prev = 0.0
+    for k in range(40000):
+        d.step()
+        d.qvel[3:6] = 0  # keep it from tumbling
+        if k % 5000 == 4999:
+            v = d.qvel[2]
+            if abs(v - v_prev) < 1e-3 * abs(v):
+                break
+            v_prev = v
+    d.forward()
+    # at terminal velocity total passive (fluid) force on the vertical root dof balances gravity
+    mass = 9.864192543522741e-4
+    assert abs(d.qacc[2]) < 0.02 * 981
+    assert 50 < -d.qvel[2] < 400  # cm/s: a ~1 mg, ~2.5 mm insect falls at the order of 1-2 m/s
+    # wings and abdomen still swing on their springs, so the balance holds to a few percent only
+    assert abs(d.qfrc_passive[2] - mass * 981) < 0.1 * mass * 981
+
+
+def test_joint_limits_hold(md):
+    m, d = md
+    m.set_flags(O.FO_NO_FLUID)
+    d.qvel[:] = 0
+    d.qvel[6:] = 50.0  # drive every hinge into its upper stop
+    from flybody_amd.model.blob import read_blob
+
+    b = read_blob(BLOB)
+    hinge = b["jnt_type"] == 3
+    rng = b["jnt_range"][hinge]
+    worst = 0.0
+    for _ in range(2000):
+        d.step()
+        q = d.qpos[7:]
+        worst = max(worst, (q - rng[:, 1]).max(), (rng[:, 0] - q).max())
+    assert worst < 0.08  # soft constraints: bounded penetration
+    assert d.nefc >= 0 and np.isfinite(d.qpos).all()
+
+
+def test_constraint_solver_satisfies_kkt(md):
+    m, d = md
+    m.set_flags(O.FO_NO_FLUID)
+    d.qvel[6:] = 30.0
+    for _ in range(300):
+        d.step()
+    d.forward()
+    assert d.nefc > 0
+    M = d.dense_M()
+    # stationarity: M (qacc - qacc_smooth) = qfrc_constraint
+    res = M @ (d.qacc - d.qacc_smooth) - d.qfrc_constraint
+    assert np.abs(res).max() < 1e-9 * max(1.0, np.abs(d.qfrc_constraint).max())
