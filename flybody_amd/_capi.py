@@ -1,0 +1,70 @@
+"""ctypes binding of include/flybody_env.h.  Fails loudly when the HIP library is missing: the product path
+has no CPU fallback."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libflybody_env.so")
+
+SYMBOLS = [
+    "ffe_create_flight", "ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step",
+    "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps",
+    "ffe_test_quat", "ffe_last_error", "ffe_version",
+]
+
+
+class FlightTask(C.Structure):
+    _fields_ = [
+        ("wb_nfreq", C.c_int32), ("wb_beat_freqs", C.POINTER(C.c_double)), ("wb_tab_off", C.POINTER(C.c_int32)),
+        ("wb_traj", C.POINTER(C.c_double)), ("wb_phase", C.POINTER(C.c_double)),
+        ("wb_base_freq", C.c_double), ("wb_rel_range", C.c_double), ("wb_rate", C.c_double), ("wb_dt_ctrl", C.c_double),
+        ("ntraj", C.c_int32), ("traj_len", C.c_int32), ("ref_qpos", C.POINTER(C.c_double)), ("ref_qvel", C.POINTER(C.c_double)),
+        ("future_steps", C.c_int32), ("time_limit_steps", C.c_int32), ("terminal_com_dist", C.c_double),
+        ("ghost_accel_z", C.c_double), ("pad_first_obs", C.c_int32), ("physics_flags", C.c_int32),
+    ]
+
+
+class Spec(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("batch", "nq", "nv", "nu", "action_dim", "obs_dim", "nsub")] + [
+        ("physics_timestep", C.c_double), ("control_timestep", C.c_double)] + [
+        (n, C.c_int32) for n in ("off_accelerometer", "off_gyro", "off_joints_pos", "off_joints_vel", "off_velocimeter",
+                                 "off_world_zaxis", "off_ref_displacement", "off_ref_root_quat", "n_obs_joints", "n_ref")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m flybody_amd.build` (hipcc, gfx950). "
+            "flybody_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, ip, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
+    L.ffe_create_flight.restype = C.c_int
+    L.ffe_create_flight.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FlightTask), C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.ffe_destroy.argtypes = [vp]
+    L.ffe_spec.argtypes = [vp, C.POINTER(Spec)]
+    L.ffe_action_bounds.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ffe_reset.argtypes = [vp, fp, fp, fp, ip, vp]
+    L.ffe_step.argtypes = [vp, fp, fp, fp, fp, ip, vp]
+    L.ffe_force_next_episode.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.ffe_get_state.argtypes = [vp, dp, dp, vp]
+    L.ffe_set_state.argtypes = [vp, dp, dp, vp]
+    L.ffe_get_task_state.argtypes = [vp, ip, dp, vp]
+    L.ffe_time_steps.argtypes = [vp, fp, fp, fp, fp, ip, C.c_int, vp, C.POINTER(C.c_float)]
+    L.ffe_test_quat.argtypes = [C.c_int, fp, fp, fp, C.c_int, vp]
+    L.ffe_last_error.restype = C.c_char_p
+    L.ffe_last_error.argtypes = [vp]
+    L.ffe_version.restype = C.c_char_p
+    for s in ("ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step", "ffe_force_next_episode", "ffe_get_state",
+              "ffe_set_state", "ffe_get_task_state", "ffe_time_steps", "ffe_test_quat"):
+        getattr(L, s).restype = C.c_int
+    _lib = L
+    return L

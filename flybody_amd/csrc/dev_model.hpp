@@ -1,0 +1,450 @@
+// dev_model.hpp - host-side construction of the device-resident model tables.
+//
+// Input: the compiled model blob (flybody_amd/model/blob.py layout).  Output: one HBM arena holding
+// lane-major ("[field][lane]") tables so that a wavefront's per-dof / per-link reads coalesce, plus the
+// index tables that drive the sparse factorisation and solves.  Everything here runs once per handle.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace ffe {
+
+constexpr int kWave = 64;
+constexpr int kMaxLink = 20;  // LDS capacity (flight model: 19)
+constexpr int kMaxDof = 44;   // LDS capacity (flight model: 42)
+constexpr int kMaxM = 424;    // LDS capacity (flight model: 421)
+constexpr int kMaxAct = 16;
+constexpr int kMaxObsJ = 32;
+constexpr int kMaxFuture = 8;
+constexpr int kLanePad = 64;  // every lane-major table is padded to a full wave
+
+// ------------------------------------------------------------------------------------------------ blob
+struct Tensor {
+  int dtype = 0;  // 0 f64, 1 i32
+  std::vector<uint32_t> dims;
+  const unsigned char *data = nullptr;
+  size_t count = 0;
+  double f(size_t i) const { double v; std::memcpy(&v, data + 8 * i, 8); return v; }
+  int32_t i(size_t k) const { int32_t v; std::memcpy(&v, data + 4 * k, 4); return v; }
+};
+
+class Blob {
+ public:
+  Blob(const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    if (n < 12 || std::memcmp(b, "FFMB", 4) != 0) throw std::runtime_error("model blob: bad magic");
+    uint32_t ver, cnt;
+    std::memcpy(&ver, b + 4, 4);
+    std::memcpy(&cnt, b + 8, 4);
+    if (ver != 1) throw std::runtime_error("model blob: unsupported version");
+    size_t off = 12;
+    for (uint32_t k = 0; k < cnt; k++) {
+      uint16_t nl;
+      if (off + 2 > n) throw std::runtime_error("model blob: truncated");
+      std::memcpy(&nl, b + off, 2); off += 2;
+      std::string name(reinterpret_cast<const char *>(b + off), nl); off += nl;
+      Tensor t;
+      t.dtype = b[off]; int ndim = b[off + 1]; off += 2;
+      t.count = 1;
+      for (int d = 0; d < ndim; d++) { uint32_t v; std::memcpy(&v, b + off, 4); off += 4; t.dims.push_back(v); t.count *= v; }
+      off += (8 - off % 8) % 8;
+      t.data = b + off;
+      off += t.count * (t.dtype == 0 ? 8 : 4);
+      if (off > n) throw std::runtime_error("model blob: truncated tensor " + name);
+      tensors_[name] = t;
+    }
+  }
+  const Tensor &get(const std::string &name) const {
+    auto it = tensors_.find(name);
+    if (it == tensors_.end()) throw std::runtime_error("model blob: missing tensor " + name);
+    return it->second;
+  }
+
+ private:
+  std::map<std::string, Tensor> tensors_;
+};
+
+// ------------------------------------------------------------------------------------------------ device view
+// Pointers into the arena (device addresses once uploaded).  Lane-major tables: element (c, lane) at [c*64+lane].
+struct DevModel {
+  int nlink, nv, nq, nu, nM, ntri, nrootrec, nobsj, nwing, naction, maxdepth, nsub;
+  float h, gx, gy, gz, total_mass;
+  // per dof
+  const int *d_parent, *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id;  // d_act_id: [2][64]
+  const float *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
+      *d_act_coef;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
+  // per link
+  const int *l_parent, *l_dofadr, *l_dofnum, *l_sub, *l_reckind, *l_recell;
+  const float *l_pos, *l_quat, *l_ipos, *l_imat, *l_inertia, *l_mass, *l_recpos, *l_recmat, *l_reccoef;
+  // fluid records on the root link, one per lane
+  const float *rr_pos, *rr_mat, *rr_coef;
+  // ellipsoid parameter blocks [nell][32]
+  const float *ell;
+  // sparse-M index tables
+  const unsigned char *m_row, *m_col;
+  const unsigned int *tri;
+  const int *tri_off;  // [nv+1]
+  // actuators
+  const int *a_trn, *a_dof, *a_qadr, *a_cl, *a_fl, *a_action, *a_wrap_off, *w_qadr, *w_dof;
+  const float *a_gain, *a_b0, *a_b1, *a_b2, *a_clo, *a_chi, *a_flo, *a_fhi, *w_coef;
+  // task bookkeeping
+  const int *wing_dof, *wing_qadr, *wing_action, *obsj_qadr, *obsj_dof;
+  int user_action;
+  const float *qpos0;  // [nq]
+};
+
+struct BoxCoef { float c[8]; };  // visc_ang, visc_lin, quad_lin[3], quad_ang[3]
+
+inline BoxCoef box_coefs(const double *box, double rho, double beta) {
+  const double kPi = 3.14159265358979323846;
+  BoxCoef o;
+  double diam = (box[0] + box[1] + box[2]) / 3.0;
+  o.c[0] = static_cast<float>(beta > 0 ? kPi * diam * diam * diam * beta : 0.0);
+  o.c[1] = static_cast<float>(beta > 0 ? 3.0 * kPi * diam * beta : 0.0);
+  o.c[2] = static_cast<float>(0.5 * rho * box[1] * box[2]);
+  o.c[3] = static_cast<float>(0.5 * rho * box[0] * box[2]);
+  o.c[4] = static_cast<float>(0.5 * rho * box[0] * box[1]);
+  o.c[5] = static_cast<float>(rho * box[0] * (std::pow(box[1], 4) + std::pow(box[2], 4)) / 64.0);
+  o.c[6] = static_cast<float>(rho * box[1] * (std::pow(box[0], 4) + std::pow(box[2], 4)) / 64.0);
+  o.c[7] = static_cast<float>(rho * box[2] * (std::pow(box[0], 4) + std::pow(box[1], 4)) / 64.0);
+  return o;
+}
+
+inline void quat2mat_d(const double *q, double *m) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+
+// Bump allocator for the arena; returns byte offsets, 16-byte aligned.
+class Arena {
+ public:
+  template <typename T>
+  size_t put(const std::vector<T> &v) {
+    size_t off = (buf_.size() + 15) & ~size_t(15);
+    buf_.resize(off + v.size() * sizeof(T) + 16);
+    std::memcpy(buf_.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+  const std::vector<unsigned char> &bytes() const { return buf_; }
+
+ private:
+  std::vector<unsigned char> buf_;
+};
+
+struct HostModel {
+  DevModel view{};           // pointers hold arena *offsets* until fixup()
+  std::vector<unsigned char> arena;
+  std::vector<float> action_min, action_max;
+  std::vector<double> qpos0;
+  int nobs = 0;
+
+  void fixup(DevModel &dst, const unsigned char *base) const {
+    dst = view;
+    auto fix = [&](auto &p) {
+      using P = std::remove_reference_t<decltype(p)>;
+      p = reinterpret_cast<P>(base + reinterpret_cast<size_t>(p));
+    };
+    fix(dst.d_parent); fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
+    fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
+    fix(dst.d_sref); fix(dst.d_lo); fix(dst.d_hi); fix(dst.d_margin); fix(dst.d_invw); fix(dst.d_K); fix(dst.d_B);
+    fix(dst.d_solimp); fix(dst.d_act_coef);
+    fix(dst.l_parent); fix(dst.l_dofadr); fix(dst.l_dofnum); fix(dst.l_sub); fix(dst.l_reckind); fix(dst.l_recell);
+    fix(dst.l_pos); fix(dst.l_quat); fix(dst.l_ipos); fix(dst.l_imat); fix(dst.l_inertia); fix(dst.l_mass);
+    fix(dst.l_recpos); fix(dst.l_recmat); fix(dst.l_reccoef);
+    fix(dst.rr_pos); fix(dst.rr_mat); fix(dst.rr_coef); fix(dst.ell);
+    fix(dst.m_row); fix(dst.m_col); fix(dst.tri); fix(dst.tri_off);
+    fix(dst.a_trn); fix(dst.a_dof); fix(dst.a_qadr); fix(dst.a_cl); fix(dst.a_fl); fix(dst.a_action);
+    fix(dst.a_wrap_off); fix(dst.w_qadr); fix(dst.w_dof);
+    fix(dst.a_gain); fix(dst.a_b0); fix(dst.a_b1); fix(dst.a_b2); fix(dst.a_clo); fix(dst.a_chi); fix(dst.a_flo);
+    fix(dst.a_fhi); fix(dst.w_coef);
+    fix(dst.wing_dof); fix(dst.wing_qadr); fix(dst.wing_action); fix(dst.obsj_qadr); fix(dst.obsj_dof);
+    fix(dst.qpos0);
+  }
+};
+
+#define FFE_OFF(T, off) reinterpret_cast<T>(static_cast<size_t>(off))
+
+inline HostModel build_host_model(const Blob &b) {
+  HostModel H;
+  DevModel &V = H.view;
+  Arena A;
+  const Tensor &opt = b.get("opt");
+  const double h = opt.f(0), rho = opt.f(1), beta = opt.f(2);
+  const Tensor &lparent = b.get("link_parent");
+  const int nl = static_cast<int>(lparent.count);
+  const Tensor &dofpar = b.get("dof_parentid");
+  const int nv = static_cast<int>(dofpar.count);
+  const int nq = static_cast<int>(b.get("qpos0").count);
+  const int nu = static_cast<int>(b.get("act_trntype").count);
+  if (nl > kMaxLink || nv > kMaxDof || nu > kMaxAct) throw std::runtime_error("model exceeds kernel capacities");
+  V.nlink = nl; V.nv = nv; V.nq = nq; V.nu = nu;
+  V.h = static_cast<float>(h);
+  V.gx = static_cast<float>(opt.f(3)); V.gy = static_cast<float>(opt.f(4)); V.gz = static_cast<float>(opt.f(5));
+
+  auto lane_f = [&](int comps) { return std::vector<float>(static_cast<size_t>(comps) * kLanePad, 0.f); };
+  auto lane_i = [&](int comps, int fill = 0) { return std::vector<int>(static_cast<size_t>(comps) * kLanePad, fill); };
+
+  // ---- body -> link / dof maps -----------------------------------------------------------------
+  const Tensor &body_link = b.get("body_link");
+  const Tensor &dof_body = b.get("dof_bodyid");
+  const Tensor &dof_jnt = b.get("dof_jntid");
+  const Tensor &jnt_type = b.get("jnt_type");
+  const Tensor &jnt_qadr = b.get("jnt_qposadr");
+  const Tensor &jnt_dadr = b.get("jnt_dofadr");
+  const Tensor &jnt_axis = b.get("jnt_axis");
+  const Tensor &jnt_pos = b.get("jnt_pos");
+  for (size_t k = 0; k < jnt_pos.count; k++)
+    if (jnt_pos.f(k) != 0.0) throw std::runtime_error("joint anchors away from the body origin are not supported");
+  if (jnt_type.i(0) != 0) throw std::runtime_error("root joint must be free");
+
+  auto d_parent = lane_i(1, -1), d_link = lane_i(1), d_madr = lane_i(1), d_depth = lane_i(1), d_kind = lane_i(1),
+       d_qadr = lane_i(1), d_limited = lane_i(1), d_act_id = lane_i(2, -1);
+  auto d_axis = lane_f(3), d_arm = lane_f(1), d_damp = lane_f(1), d_stiff = lane_f(1), d_sref = lane_f(1),
+       d_lo = lane_f(1), d_hi = lane_f(1), d_margin = lane_f(1), d_invw = lane_f(1), d_K = lane_f(1), d_B = lane_f(1),
+       d_solimp = lane_f(5), d_act_coef = lane_f(2);
+  std::vector<unsigned char> m_row, m_col;
+  int maxdepth = 0;
+  for (int d = 0; d < nv; d++) {
+    d_parent[d] = dofpar.i(d);
+    d_link[d] = body_link.i(dof_body.i(d));
+    int j = dof_jnt.i(d), jt = jnt_type.i(j);
+    int within = d - jnt_dadr.i(j);
+    if (jt == 0) { d_kind[d] = within < 3 ? 0 : 1; d_qadr[d] = within % 3; }
+    else if (jt == 3) { d_kind[d] = 2; d_qadr[d] = jnt_qadr.i(j); }
+    else throw std::runtime_error("only free and hinge joints are supported");
+    for (int c = 0; c < 3; c++) d_axis[c * kLanePad + d] = static_cast<float>(jnt_axis.f(3 * j + c));
+    d_arm[d] = static_cast<float>(b.get("dof_armature").f(d));
+    d_damp[d] = static_cast<float>(b.get("dof_damping").f(d));
+    d_invw[d] = static_cast<float>(b.get("dof_invweight0").f(d));
+    if (jt == 3) {
+      d_stiff[d] = static_cast<float>(b.get("jnt_stiffness").f(j));
+      d_sref[d] = static_cast<float>(b.get("qpos_spring").f(jnt_qadr.i(j)));
+      d_limited[d] = b.get("jnt_limited").i(j);
+      d_lo[d] = static_cast<float>(b.get("jnt_range").f(2 * j));
+      d_hi[d] = static_cast<float>(b.get("jnt_range").f(2 * j + 1));
+      d_margin[d] = static_cast<float>(b.get("jnt_margin").f(j));
+      const Tensor &si = b.get("jnt_solimp"), &sr = b.get("jnt_solref");
+      double s[5];
+      for (int c = 0; c < 5; c++) s[c] = si.f(5 * j + c);
+      s[0] = std::fmin(std::fmax(s[0], 1e-4), 0.9999); s[1] = std::fmin(std::fmax(s[1], 1e-4), 0.9999);
+      s[2] = std::fmax(0.0, s[2]); s[3] = std::fmin(std::fmax(s[3], 1e-4), 0.9999); s[4] = std::fmax(1.0, s[4]);
+      for (int c = 0; c < 5; c++) d_solimp[c * kLanePad + d] = static_cast<float>(s[c]);
+      double tc = sr.f(2 * j), dr = sr.f(2 * j + 1), dmax = s[1], K, B;
+      if (tc > 0) {
+        tc = std::fmax(tc, 2 * h);  // refsafe
+        K = 1.0 / std::fmax(1e-15, dmax * dmax * tc * tc * dr * dr);
+        B = 2.0 / std::fmax(1e-15, dmax * tc);
+      } else { K = -tc / std::fmax(1e-15, dmax * dmax); B = -dr / std::fmax(1e-15, dmax); }
+      d_K[d] = static_cast<float>(K); d_B[d] = static_cast<float>(B);
+    }
+    d_madr[d] = static_cast<int>(m_row.size());
+    int depth = 0;
+    for (int a = d; a >= 0; a = dofpar.i(a)) { m_row.push_back(static_cast<unsigned char>(d)); m_col.push_back(static_cast<unsigned char>(a)); depth++; }
+    d_depth[d] = depth;
+    maxdepth = depth > maxdepth ? depth : maxdepth;
+  }
+  const int nM = static_cast<int>(m_row.size());
+  if (nM > kMaxM) throw std::runtime_error("mass matrix exceeds kernel capacity");
+  V.nM = nM; V.maxdepth = maxdepth;
+  // elimination triples: for pivot k with ancestors a_1..a_n: M(a_s, a_t) -= M(k,a_s) M(k,a_t) / M(k,k), s <= t
+  std::vector<unsigned int> tri;
+  std::vector<int> tri_off(nv + 1, 0);
+  for (int k = 0; k < nv; k++) {
+    tri_off[k] = static_cast<int>(tri.size());
+    std::vector<int> anc;
+    for (int a = dofpar.i(k); a >= 0; a = dofpar.i(a)) anc.push_back(a);
+    int n = static_cast<int>(anc.size());
+    for (int s = 1; s <= n; s++)
+      for (int t = s; t <= n; t++) {
+        unsigned tgt = static_cast<unsigned>(d_madr[anc[s - 1]] + (t - s));
+        tri.push_back((tgt << 16) | (static_cast<unsigned>(s) << 8) | static_cast<unsigned>(t));
+      }
+  }
+  tri_off[nv] = static_cast<int>(tri.size());
+  V.ntri = static_cast<int>(tri.size());
+
+  // ---- links ---------------------------------------------------------------------------------------
+  auto l_parent = lane_i(1, -1), l_dofadr = lane_i(1), l_dofnum = lane_i(1), l_sub = lane_i(1), l_reckind = lane_i(1),
+       l_recell = lane_i(1);
+  auto l_pos = lane_f(3), l_quat = lane_f(4), l_ipos = lane_f(3), l_imat = lane_f(9), l_inertia = lane_f(3),
+       l_mass = lane_f(1), l_recpos = lane_f(3), l_recmat = lane_f(9), l_reccoef = lane_f(8);
+  double total_mass = 0;
+  for (int k = 0; k < nl; k++) {
+    l_parent[k] = lparent.i(k);
+    l_dofadr[k] = b.get("link_dofadr").i(k);
+    l_dofnum[k] = b.get("link_dofnum").i(k);
+    l_sub[k] = b.get("link_subtree").i(k);
+    for (int c = 0; c < 3; c++) l_pos[c * kLanePad + k] = static_cast<float>(b.get("link_pos").f(3 * k + c));
+    for (int c = 0; c < 4; c++) l_quat[c * kLanePad + k] = static_cast<float>(b.get("link_quat").f(4 * k + c));
+    for (int c = 0; c < 3; c++) l_ipos[c * kLanePad + k] = static_cast<float>(b.get("link_ipos").f(3 * k + c));
+    double q[4], mat[9];
+    for (int c = 0; c < 4; c++) q[c] = b.get("link_iquat").f(4 * k + c);
+    quat2mat_d(q, mat);
+    for (int c = 0; c < 9; c++) l_imat[c * kLanePad + k] = static_cast<float>(mat[c]);
+    for (int c = 0; c < 3; c++) l_inertia[c * kLanePad + k] = static_cast<float>(b.get("link_inertia").f(3 * k + c));
+    l_mass[k] = static_cast<float>(b.get("link_mass").f(k));
+    total_mass += b.get("link_mass").f(k);
+  }
+  V.total_mass = static_cast<float>(total_mass);
+  // fluid records: root link's go one per lane, every other link carries at most one record of its own
+  auto rr_pos = lane_f(3), rr_mat = lane_f(9), rr_coef = lane_f(8);
+  int nrr = 0;
+  const Tensor &fb_link = b.get("fbox_link");
+  for (size_t r = 0; r < fb_link.count; r++) {
+    int k = fb_link.i(r);
+    BoxCoef bc = box_coefs(reinterpret_cast<const double *>(b.get("fbox_box").data) + 3 * r, rho, beta);
+    if (k == 0) {
+      if (nrr >= kWave) throw std::runtime_error("too many fluid records on the root link");
+      for (int c = 0; c < 3; c++) rr_pos[c * kLanePad + nrr] = static_cast<float>(b.get("fbox_pos").f(3 * r + c));
+      for (int c = 0; c < 9; c++) rr_mat[c * kLanePad + nrr] = static_cast<float>(b.get("fbox_mat").f(9 * r + c));
+      for (int c = 0; c < 8; c++) rr_coef[c * kLanePad + nrr] = bc.c[c];
+      nrr++;
+    } else {
+      if (l_reckind[k] != 0) throw std::runtime_error("more than one fluid record on a non-root link");
+      l_reckind[k] = 1;
+      for (int c = 0; c < 3; c++) l_recpos[c * kLanePad + k] = static_cast<float>(b.get("fbox_pos").f(3 * r + c));
+      for (int c = 0; c < 9; c++) l_recmat[c * kLanePad + k] = static_cast<float>(b.get("fbox_mat").f(9 * r + c));
+      for (int c = 0; c < 8; c++) l_reccoef[c * kLanePad + k] = bc.c[c];
+    }
+  }
+  V.nrootrec = nrr;
+  const Tensor &fe_link = b.get("fell_link");
+  std::vector<float> ell(32 * (fe_link.count ? fe_link.count : 1), 0.f);
+  const double kPi = 3.14159265358979323846;
+  for (size_t g = 0; g < fe_link.count; g++) {
+    int k = fe_link.i(g);
+    if (k == 0 || l_reckind[k] != 0) throw std::runtime_error("unsupported ellipsoid fluid geom placement");
+    l_reckind[k] = 2; l_recell[k] = static_cast<int>(g);
+    for (int c = 0; c < 3; c++) l_recpos[c * kLanePad + k] = static_cast<float>(b.get("fell_pos").f(3 * g + c));
+    for (int c = 0; c < 9; c++) l_recmat[c * kLanePad + k] = static_cast<float>(b.get("fell_mat").f(9 * g + c));
+    const double *s = reinterpret_cast<const double *>(b.get("fell_size").data) + 3 * g;
+    const double *cf = reinterpret_cast<const double *>(b.get("fell_coef").data) + 12 * g;
+    double dmax = std::fmax(std::fmax(s[0], s[1]), s[2]), dmin = std::fmin(std::fmin(s[0], s[1]), s[2]);
+    double dmid = s[0] + s[1] + s[2] - dmax - dmin;
+    double vol = 4.0 / 3.0 * kPi * s[0] * s[1] * s[2], eqD = 2.0 / 3.0 * (s[0] + s[1] + s[2]);
+    float *e = ell.data() + 32 * g;
+    e[0] = static_cast<float>(cf[0]);                                  // interaction coefficient
+    for (int c = 0; c < 3; c++) e[1 + c] = static_cast<float>(rho * cf[6 + c]);   // rho * virtual mass
+    for (int c = 0; c < 3; c++) e[4 + c] = static_cast<float>(rho * cf[9 + c]);   // rho * virtual inertia
+    e[7] = static_cast<float>(cf[5] * rho * vol);                      // Magnus
+    e[8] = static_cast<float>(s[1] * s[2]); e[9] = static_cast<float>(s[2] * s[0]); e[10] = static_cast<float>(s[0] * s[1]);
+    e[11] = static_cast<float>(cf[4] * rho);                           // Kutta
+    e[12] = static_cast<float>(kPi * dmax * dmid);                     // A_max
+    e[13] = static_cast<float>(cf[1]); e[14] = static_cast<float>(cf[2]); e[15] = static_cast<float>(cf[3]);  // blunt, slender, angular
+    e[16] = static_cast<float>(beta * 3.0 * kPi * eqD);
+    e[17] = static_cast<float>(beta * kPi * eqD * eqD * eqD);
+    e[18] = static_cast<float>(8.0 / 15.0 * kPi * dmid * dmax * dmax * dmax * dmax);  // I_max
+    e[19] = static_cast<float>(8.0 / 15.0 * kPi * s[0] * std::pow(std::fmax(s[1], s[2]), 4));
+    e[20] = static_cast<float>(8.0 / 15.0 * kPi * s[1] * std::pow(std::fmax(s[0], s[2]), 4));
+    e[21] = static_cast<float>(8.0 / 15.0 * kPi * s[2] * std::pow(std::fmax(s[0], s[1]), 4));
+    e[22] = static_cast<float>(rho);
+  }
+
+  // ---- actuators -----------------------------------------------------------------------------------
+  std::vector<int> a_trn(kMaxAct, 0), a_dof(kMaxAct, 0), a_qadr(kMaxAct, 0), a_cl(kMaxAct, 0), a_fl(kMaxAct, 0),
+      a_action(kMaxAct, -1), a_wrap_off(kMaxAct + 1, 0), w_qadr, w_dof;
+  std::vector<float> a_gain(kMaxAct, 0), a_b0(kMaxAct, 0), a_b1(kMaxAct, 0), a_b2(kMaxAct, 0), a_clo(kMaxAct, 0),
+      a_chi(kMaxAct, 0), a_flo(kMaxAct, 0), a_fhi(kMaxAct, 0), w_coef;
+  const Tensor &ten_adr = b.get("ten_adr"), &ten_num = b.get("ten_num"), &wrap_dof = b.get("wrap_dof"), &wrap_coef = b.get("wrap_coef");
+  auto add_coupling = [&](int dof, int act, float coef) {
+    for (int s = 0; s < 2; s++)
+      if (d_act_id[s * kLanePad + dof] < 0) { d_act_id[s * kLanePad + dof] = act; d_act_coef[s * kLanePad + dof] = coef; return; }
+    throw std::runtime_error("more than two actuators drive one dof");
+  };
+  for (int u = 0; u < nu; u++) {
+    int trn = b.get("act_trntype").i(u), id = b.get("act_trnid").i(u);
+    double gear = b.get("act_gear").f(u);
+    if (b.get("act_dyntype").i(u) != 0) throw std::runtime_error("actuator activation dynamics are not supported yet");
+    a_trn[u] = trn;
+    a_gain[u] = static_cast<float>(b.get("act_gainprm").f(u));
+    a_b0[u] = static_cast<float>(b.get("act_biasprm").f(3 * u));
+    a_b1[u] = static_cast<float>(b.get("act_biasprm").f(3 * u + 1) * gear);
+    a_b2[u] = static_cast<float>(b.get("act_biasprm").f(3 * u + 2) * gear);
+    a_cl[u] = b.get("act_ctrllimited").i(u);
+    a_clo[u] = static_cast<float>(b.get("act_ctrlrange").f(2 * u)); a_chi[u] = static_cast<float>(b.get("act_ctrlrange").f(2 * u + 1));
+    a_fl[u] = b.get("act_forcelimited").i(u);
+    a_flo[u] = static_cast<float>(b.get("act_forcerange").f(2 * u)); a_fhi[u] = static_cast<float>(b.get("act_forcerange").f(2 * u + 1));
+    a_action[u] = b.get("act_action").i(u);
+    a_wrap_off[u] = static_cast<int>(w_qadr.size());
+    if (trn == 0) {
+      a_dof[u] = jnt_dadr.i(id); a_qadr[u] = jnt_qadr.i(id);
+      add_coupling(a_dof[u], u, static_cast<float>(gear));
+    } else if (trn == 1) {
+      for (int w = ten_adr.i(id); w < ten_adr.i(id) + ten_num.i(id); w++) {
+        int dof = wrap_dof.i(w);
+        w_dof.push_back(dof); w_qadr.push_back(jnt_qadr.i(dof_jnt.i(dof))); w_coef.push_back(static_cast<float>(wrap_coef.f(w)));
+        add_coupling(dof, u, static_cast<float>(gear * wrap_coef.f(w)));
+      }
+    } else throw std::runtime_error("body (adhesion) transmissions are not supported yet");
+  }
+  for (int u = nu; u <= kMaxAct; u++) a_wrap_off[u] = static_cast<int>(w_qadr.size());
+  if (w_qadr.empty()) { w_qadr.push_back(0); w_dof.push_back(0); w_coef.push_back(0.f); }
+
+  // ---- task bookkeeping ----------------------------------------------------------------------------
+  const Tensor &wing_jnt = b.get("wing_jnt"), &wing_act = b.get("wing_action"), &obs_jnt = b.get("obs_jnt");
+  std::vector<int> wing_dof(8, 0), wing_qadr(8, 0), wing_action(8, 0), obsj_qadr(kMaxObsJ, 0), obsj_dof(kMaxObsJ, 0);
+  V.nwing = static_cast<int>(wing_jnt.count);
+  for (int k = 0; k < V.nwing; k++) { wing_dof[k] = jnt_dadr.i(wing_jnt.i(k)); wing_qadr[k] = jnt_qadr.i(wing_jnt.i(k)); wing_action[k] = wing_act.i(k); }
+  V.nobsj = static_cast<int>(obs_jnt.count);
+  if (V.nobsj > kMaxObsJ) throw std::runtime_error("too many observable joints");
+  for (int k = 0; k < V.nobsj; k++) { obsj_qadr[k] = jnt_qadr.i(obs_jnt.i(k)); obsj_dof[k] = jnt_dadr.i(obs_jnt.i(k)); }
+  V.user_action = b.get("user_action").count ? b.get("user_action").i(0) : -1;
+  V.naction = static_cast<int>(b.get("action_min").count);
+  for (int k = 0; k < V.naction; k++) { H.action_min.push_back(static_cast<float>(b.get("action_min").f(k))); H.action_max.push_back(static_cast<float>(b.get("action_max").f(k))); }
+  std::vector<float> qpos0(nq);
+  for (int k = 0; k < nq; k++) { qpos0[k] = static_cast<float>(b.get("qpos0").f(k)); H.qpos0.push_back(b.get("qpos0").f(k)); }
+  const Tensor &site = b.get("site");
+  for (int c = 1; c <= 3; c++) if (site.f(c) != 0.0) throw std::runtime_error("sensor site must sit at the root body origin");
+  if (site.f(4) != 1.0) throw std::runtime_error("sensor site must share the root body orientation");
+
+  // ---- pack ------------------------------------------------------------------------------------------
+  V.d_parent = FFE_OFF(const int *, A.put(d_parent)); V.d_link = FFE_OFF(const int *, A.put(d_link));
+  V.d_madr = FFE_OFF(const int *, A.put(d_madr)); V.d_depth = FFE_OFF(const int *, A.put(d_depth));
+  V.d_kind = FFE_OFF(const int *, A.put(d_kind)); V.d_qadr = FFE_OFF(const int *, A.put(d_qadr));
+  V.d_limited = FFE_OFF(const int *, A.put(d_limited)); V.d_act_id = FFE_OFF(const int *, A.put(d_act_id));
+  V.d_axis = FFE_OFF(const float *, A.put(d_axis)); V.d_arm = FFE_OFF(const float *, A.put(d_arm));
+  V.d_damp = FFE_OFF(const float *, A.put(d_damp)); V.d_stiff = FFE_OFF(const float *, A.put(d_stiff));
+  V.d_sref = FFE_OFF(const float *, A.put(d_sref)); V.d_lo = FFE_OFF(const float *, A.put(d_lo));
+  V.d_hi = FFE_OFF(const float *, A.put(d_hi)); V.d_margin = FFE_OFF(const float *, A.put(d_margin));
+  V.d_invw = FFE_OFF(const float *, A.put(d_invw)); V.d_K = FFE_OFF(const float *, A.put(d_K));
+  V.d_B = FFE_OFF(const float *, A.put(d_B)); V.d_solimp = FFE_OFF(const float *, A.put(d_solimp));
+  V.d_act_coef = FFE_OFF(const float *, A.put(d_act_coef));
+  V.l_parent = FFE_OFF(const int *, A.put(l_parent)); V.l_dofadr = FFE_OFF(const int *, A.put(l_dofadr));
+  V.l_dofnum = FFE_OFF(const int *, A.put(l_dofnum)); V.l_sub = FFE_OFF(const int *, A.put(l_sub));
+  V.l_reckind = FFE_OFF(const int *, A.put(l_reckind)); V.l_recell = FFE_OFF(const int *, A.put(l_recell));
+  V.l_pos = FFE_OFF(const float *, A.put(l_pos)); V.l_quat = FFE_OFF(const float *, A.put(l_quat));
+  V.l_ipos = FFE_OFF(const float *, A.put(l_ipos)); V.l_imat = FFE_OFF(const float *, A.put(l_imat));
+  V.l_inertia = FFE_OFF(const float *, A.put(l_inertia)); V.l_mass = FFE_OFF(const float *, A.put(l_mass));
+  V.l_recpos = FFE_OFF(const float *, A.put(l_recpos)); V.l_recmat = FFE_OFF(const float *, A.put(l_recmat));
+  V.l_reccoef = FFE_OFF(const float *, A.put(l_reccoef));
+  V.rr_pos = FFE_OFF(const float *, A.put(rr_pos)); V.rr_mat = FFE_OFF(const float *, A.put(rr_mat));
+  V.rr_coef = FFE_OFF(const float *, A.put(rr_coef)); V.ell = FFE_OFF(const float *, A.put(ell));
+  V.m_row = FFE_OFF(const unsigned char *, A.put(m_row)); V.m_col = FFE_OFF(const unsigned char *, A.put(m_col));
+  V.tri = FFE_OFF(const unsigned int *, A.put(tri)); V.tri_off = FFE_OFF(const int *, A.put(tri_off));
+  V.a_trn = FFE_OFF(const int *, A.put(a_trn)); V.a_dof = FFE_OFF(const int *, A.put(a_dof));
+  V.a_qadr = FFE_OFF(const int *, A.put(a_qadr)); V.a_cl = FFE_OFF(const int *, A.put(a_cl));
+  V.a_fl = FFE_OFF(const int *, A.put(a_fl)); V.a_action = FFE_OFF(const int *, A.put(a_action));
+  V.a_wrap_off = FFE_OFF(const int *, A.put(a_wrap_off)); V.w_qadr = FFE_OFF(const int *, A.put(w_qadr));
+  V.w_dof = FFE_OFF(const int *, A.put(w_dof));
+  V.a_gain = FFE_OFF(const float *, A.put(a_gain)); V.a_b0 = FFE_OFF(const float *, A.put(a_b0));
+  V.a_b1 = FFE_OFF(const float *, A.put(a_b1)); V.a_b2 = FFE_OFF(const float *, A.put(a_b2));
+  V.a_clo = FFE_OFF(const float *, A.put(a_clo)); V.a_chi = FFE_OFF(const float *, A.put(a_chi));
+  V.a_flo = FFE_OFF(const float *, A.put(a_flo)); V.a_fhi = FFE_OFF(const float *, A.put(a_fhi));
+  V.w_coef = FFE_OFF(const float *, A.put(w_coef));
+  V.wing_dof = FFE_OFF(const int *, A.put(wing_dof)); V.wing_qadr = FFE_OFF(const int *, A.put(wing_qadr));
+  V.wing_action = FFE_OFF(const int *, A.put(wing_action));
+  V.obsj_qadr = FFE_OFF(const int *, A.put(obsj_qadr)); V.obsj_dof = FFE_OFF(const int *, A.put(obsj_dof));
+  V.qpos0 = FFE_OFF(const float *, A.put(qpos0));
+  H.arena = A.bytes();
+  return H;
+}
+
+}  // namespace ffe

@@ -1,0 +1,1184 @@
+// fly_env.hip - MI355X (gfx950) batched fruit-fly environment: HIP kernels + the C ABI of
+// include/flybody_env.h.
+//
+// Execution model: ONE 64-lane wavefront per environment instance, one workgroup = one wavefront, one
+// launch = one control step of every env (task pre-step, nsub physics substeps, observation, reward,
+// termination, auto-reset), so an env's state leaves the chip once per control step.
+//   lanes <-> dofs (42)            for joint-space work (forces, limits, integration),
+//   lanes <-> links (19)           for body-space work (kinematics, spatial inertia, velocities, forces),
+//   lanes <-> fluid records (49)   for the inertia-box drag of the bodies welded to the thorax,
+//   lanes <-> M entries (421, 7/lane) for the joint-space inertia,
+// with per-env tiles (spatial quantities, M, its factor) staged in LDS and tree passes written as
+// gather-sums over precomputed ancestor / subtree ranges so that a pass needs one LDS barrier, not one
+// per tree level.  Reference semantics being reproduced are cited inline ("ref:" = /root/reference/vnl_ray,
+// "mj:" = the MuJoCo stage the reference reaches through dm_control).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/flybody_env.h"
+#include "dev_model.hpp"
+
+namespace ffe {
+
+// ------------------------------------------------------------------------------------------------ state
+struct alignas(64) EnvState {
+  double rootpos[3];
+  double wb_ctrl_freq;
+  double ghost[8];  // pos[3], quat[4], pad
+  double forced_phase;
+  unsigned long long episode, lo_mask, hi_mask;
+  float qpos[kMaxDof + 4];  // [0..2] unused (root position is held in float64 above), [3..6] root quat, hinges
+  float qvel[kMaxDof + 4];
+  int wb_step, wb_freq_idx, step_counter, traj_idx, needs_reset, nactive, solver_iters, forced_traj;
+};
+
+struct TaskDev {
+  int nfreq, ntraj, traj_len, future_steps, time_limit_steps, pad_first_obs, flags, obs_dim;
+  double base_freq, rel_range, rate, dt_ctrl, terminal_com_dist, ghost_accel_z;
+  const double *beat_freqs, *phase, *phase_frac, *ref_qpos, *ref_qvel;
+  const float *traj;
+  const int *tab_off;
+  unsigned long long seed, env_id_base;
+};
+
+// ------------------------------------------------------------------------------------------------ LDS tile
+struct alignas(16) Tile {
+  float qpos[kMaxDof + 4];
+  float qvel[kMaxDof + 4];
+  float lT[kMaxLink][8];      // link frame in its parent link: pos[3], quat[4]
+  float xpos[kMaxLink][4];    // world (root-relative) link origin
+  float xmat[kMaxLink][12];   // world link orientation (9 used)
+  float cinert[kMaxLink][12]; // 10 used
+  float crb[kMaxLink][12];
+  float cdof[kMaxDof][8];     // 6 used
+  float cdofd[kMaxDof][8];
+  float buf[kMaxDof][8];
+  float la[kMaxLink][8];      // per-link scratch (6 used)
+  float lb[kMaxLink][8];
+  float lc[kMaxLink][8];
+  float M[kMaxM];
+  float LD[kMaxM];
+  float dinv[kLanePad];
+  float x[kLanePad];
+  float frc[kMaxAct];
+};
+
+// ------------------------------------------------------------------------------------------------ maths
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+struct S6 { float a0, a1, a2, l0, l1, l2; };  // spatial vector: angular then linear
+struct M3 { float m0, m1, m2, m3, m4, m5, m6, m7, m8; };
+
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qconj(Q4 q) { return {q.w, -q.x, -q.y, -q.z}; }
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < 1e-15f) return {1.f, 0.f, 0.f, 0.f};
+  float r = 1.0f / n;
+  return {q.w * r, q.x * r, q.y * r, q.z * r};
+}
+__device__ __forceinline__ M3 q2m(Q4 q) {
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  return {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+          2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+          2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
+}
+__device__ __forceinline__ V3 mv(const M3 &m, V3 v) {
+  return {m.m0 * v.x + m.m1 * v.y + m.m2 * v.z, m.m3 * v.x + m.m4 * v.y + m.m5 * v.z, m.m6 * v.x + m.m7 * v.y + m.m8 * v.z};
+}
+__device__ __forceinline__ V3 mtv(const M3 &m, V3 v) {
+  return {m.m0 * v.x + m.m3 * v.y + m.m6 * v.z, m.m1 * v.x + m.m4 * v.y + m.m7 * v.z, m.m2 * v.x + m.m5 * v.y + m.m8 * v.z};
+}
+__device__ __forceinline__ M3 mm(const M3 &a, const M3 &b) {
+  return {a.m0 * b.m0 + a.m1 * b.m3 + a.m2 * b.m6, a.m0 * b.m1 + a.m1 * b.m4 + a.m2 * b.m7, a.m0 * b.m2 + a.m1 * b.m5 + a.m2 * b.m8,
+          a.m3 * b.m0 + a.m4 * b.m3 + a.m5 * b.m6, a.m3 * b.m1 + a.m4 * b.m4 + a.m5 * b.m7, a.m3 * b.m2 + a.m4 * b.m5 + a.m5 * b.m8,
+          a.m6 * b.m0 + a.m7 * b.m3 + a.m8 * b.m6, a.m6 * b.m1 + a.m7 * b.m4 + a.m8 * b.m7, a.m6 * b.m2 + a.m7 * b.m5 + a.m8 * b.m8};
+}
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) { return mv(q2m(q), v); }  // mj: mju_rotVecQuat
+__device__ __forceinline__ Q4 axis_angle(V3 ax, float ang) {
+  float s, c;
+  sincosf(0.5f * ang, &s, &c);
+  return {c, ax.x * s, ax.y * s, ax.z * s};
+}
+__device__ __forceinline__ S6 operator+(S6 a, S6 b) { return {a.a0 + b.a0, a.a1 + b.a1, a.a2 + b.a2, a.l0 + b.l0, a.l1 + b.l1, a.l2 + b.l2}; }
+__device__ __forceinline__ S6 operator-(S6 a, S6 b) { return {a.a0 - b.a0, a.a1 - b.a1, a.a2 - b.a2, a.l0 - b.l0, a.l1 - b.l1, a.l2 - b.l2}; }
+__device__ __forceinline__ S6 operator*(float s, S6 a) { return {s * a.a0, s * a.a1, s * a.a2, s * a.l0, s * a.l1, s * a.l2}; }
+__device__ __forceinline__ float dot6(S6 a, S6 b) { return a.a0 * b.a0 + a.a1 * b.a1 + a.a2 * b.a2 + a.l0 * b.l0 + a.l1 * b.l1 + a.l2 * b.l2; }
+__device__ __forceinline__ V3 ang(S6 s) { return {s.a0, s.a1, s.a2}; }
+__device__ __forceinline__ V3 lin(S6 s) { return {s.l0, s.l1, s.l2}; }
+__device__ __forceinline__ S6 mk6(V3 a, V3 l) { return {a.x, a.y, a.z, l.x, l.y, l.z}; }
+__device__ __forceinline__ S6 zero6() { return {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+// mj: mju_crossMotion / mju_crossForce
+__device__ __forceinline__ S6 cross_motion(S6 vel, S6 v) { return mk6(cross(ang(vel), ang(v)), cross(ang(vel), lin(v)) + cross(lin(vel), ang(v))); }
+__device__ __forceinline__ S6 cross_force(S6 vel, S6 f) { return mk6(cross(ang(vel), ang(f)) + cross(lin(vel), lin(f)), cross(ang(vel), lin(f))); }
+__device__ __forceinline__ S6 ld6(const float *p) { return {p[0], p[1], p[2], p[3], p[4], p[5]}; }
+__device__ __forceinline__ void st6(float *p, S6 s) { p[0] = s.a0; p[1] = s.a1; p[2] = s.a2; p[3] = s.l0; p[4] = s.l1; p[5] = s.l2; }
+__device__ __forceinline__ M3 ldm(const float *p) { return {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]}; }
+__device__ __forceinline__ M3 ldm_lane(const float *tab, int lane) {
+  return {tab[0 * kLanePad + lane], tab[1 * kLanePad + lane], tab[2 * kLanePad + lane], tab[3 * kLanePad + lane], tab[4 * kLanePad + lane],
+          tab[5 * kLanePad + lane], tab[6 * kLanePad + lane], tab[7 * kLanePad + lane], tab[8 * kLanePad + lane]};
+}
+__device__ __forceinline__ V3 ldv_lane(const float *tab, int lane) { return {tab[lane], tab[kLanePad + lane], tab[2 * kLanePad + lane]}; }
+
+struct I10 { float i0, i1, i2, i3, i4, i5, i6, i7, i8, i9; };
+__device__ __forceinline__ I10 ld10(const float *p) { return {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9]}; }
+__device__ __forceinline__ void st10(float *p, const I10 &i) { p[0] = i.i0; p[1] = i.i1; p[2] = i.i2; p[3] = i.i3; p[4] = i.i4; p[5] = i.i5; p[6] = i.i6; p[7] = i.i7; p[8] = i.i8; p[9] = i.i9; }
+__device__ __forceinline__ I10 add10(const I10 &a, const I10 &b) { return {a.i0 + b.i0, a.i1 + b.i1, a.i2 + b.i2, a.i3 + b.i3, a.i4 + b.i4, a.i5 + b.i5, a.i6 + b.i6, a.i7 + b.i7, a.i8 + b.i8, a.i9 + b.i9}; }
+// mj: mju_inertCom
+__device__ __forceinline__ I10 inert_com(V3 in, const M3 &R, V3 d, float mass) {
+  float t0 = R.m0 * in.x, t1 = R.m1 * in.y, t2 = R.m2 * in.z, t3 = R.m3 * in.x, t4 = R.m4 * in.y, t5 = R.m5 * in.z, t6 = R.m6 * in.x,
+        t7 = R.m7 * in.y, t8 = R.m8 * in.z;
+  float XX = t0 * R.m0 + t1 * R.m1 + t2 * R.m2, YY = t3 * R.m3 + t4 * R.m4 + t5 * R.m5, ZZ = t6 * R.m6 + t7 * R.m7 + t8 * R.m8;
+  float XY = t0 * R.m3 + t1 * R.m4 + t2 * R.m5, XZ = t0 * R.m6 + t1 * R.m7 + t2 * R.m8, YZ = t3 * R.m6 + t4 * R.m7 + t5 * R.m8;
+  return {XX + mass * (d.y * d.y + d.z * d.z), YY + mass * (d.x * d.x + d.z * d.z), ZZ + mass * (d.x * d.x + d.y * d.y),
+          XY - mass * d.x * d.y, XZ - mass * d.x * d.z, YZ - mass * d.y * d.z, mass * d.x, mass * d.y, mass * d.z, mass};
+}
+// mj: mju_mulInertVec
+__device__ __forceinline__ S6 mul_inert(const I10 &i, S6 v) {
+  return {i.i0 * v.a0 + i.i3 * v.a1 + i.i4 * v.a2 - i.i8 * v.l1 + i.i7 * v.l2, i.i3 * v.a0 + i.i1 * v.a1 + i.i5 * v.a2 + i.i8 * v.l0 - i.i6 * v.l2,
+          i.i4 * v.a0 + i.i5 * v.a1 + i.i2 * v.a2 - i.i7 * v.l0 + i.i6 * v.l1, i.i8 * v.a1 - i.i7 * v.a2 + i.i9 * v.l0,
+          i.i6 * v.a2 - i.i8 * v.a0 + i.i9 * v.l1, i.i7 * v.a0 - i.i6 * v.a1 + i.i9 * v.l2};
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ S6 wave_sum6(S6 s) { return {wave_sum(s.a0), wave_sum(s.a1), wave_sum(s.a2), wave_sum(s.l0), wave_sum(s.l1), wave_sum(s.l2)}; }
+
+// ref: quaternions.py:88-102 / :46-69 / :105-134 / :273-295 / :13-17 (float32 device versions)
+__device__ __forceinline__ Q4 quat_recip(Q4 q) {
+  float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  return {q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
+}
+__device__ __forceinline__ V3 rotate_vec_with_quat(V3 v, Q4 q) {
+  Q4 r = qmul(q, qmul(Q4{0.f, v.x, v.y, v.z}, quat_recip(q)));
+  return {r.x, r.y, r.z};
+}
+__device__ __forceinline__ float quat_dist_short_arc(Q4 a, Q4 b) {
+  float na = sqrtf(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z), nb = sqrtf(b.w * b.w + b.x * b.x + b.y * b.y + b.z * b.z);
+  float dp = (a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z) / (na * nb);
+  float x = fminf(1.0f, 2.f * dp * dp - 1.f);
+  return acosf(x);
+}
+
+// mj: inertia-box fluid model (mj_inertiaBoxFluidModel) for one body whose inertial frame sits at `rpos`
+// (link coordinates) with axes `rmat` (link coordinates).  Returns the wrench about the com reference point.
+__device__ __forceinline__ S6 box_fluid(const float *coef, int lane, V3 rpos, const M3 &rmat, V3 xpos, const M3 &xmat, S6 cvel, V3 com) {
+  V3 p = xpos + mv(xmat, rpos);
+  M3 R = mm(xmat, rmat);
+  V3 dif = p - com;
+  V3 w = ang(cvel), v = lin(cvel) - cross(dif, w);
+  V3 lw = mtv(R, w), lv = mtv(R, v);
+  float c0 = coef[0 * kLanePad + lane], c1 = coef[1 * kLanePad + lane];
+  V3 lt = {-c0 * lw.x - coef[5 * kLanePad + lane] * fabsf(lw.x) * lw.x, -c0 * lw.y - coef[6 * kLanePad + lane] * fabsf(lw.y) * lw.y,
+           -c0 * lw.z - coef[7 * kLanePad + lane] * fabsf(lw.z) * lw.z};
+  V3 lf = {-c1 * lv.x - coef[2 * kLanePad + lane] * fabsf(lv.x) * lv.x, -c1 * lv.y - coef[3 * kLanePad + lane] * fabsf(lv.y) * lv.y,
+           -c1 * lv.z - coef[4 * kLanePad + lane] * fabsf(lv.z) * lv.z};
+  V3 t = mv(R, lt), f = mv(R, lf);
+  return mk6(t + cross(dif, f), f);
+}
+// mj: ellipsoid fluid model (mj_ellipsoidFluidModel + mj_addedMassForces + mj_viscousForces)
+__device__ __forceinline__ S6 ell_fluid(const float *e, V3 rpos, const M3 &rmat, V3 xpos, const M3 &xmat, S6 cvel, V3 com) {
+  V3 p = xpos + mv(xmat, rpos);
+  M3 R = mm(xmat, rmat);
+  V3 dif = p - com;
+  V3 ww = ang(cvel), vv = lin(cvel) - cross(dif, ww);
+  V3 w = mtv(R, ww), v = mtv(R, vv);
+  V3 plin = {e[1] * v.x, e[2] * v.y, e[3] * v.z}, pang = {e[4] * w.x, e[5] * w.y, e[6] * w.z};
+  V3 f = cross(plin, w);
+  V3 t = cross(plin, v) + cross(pang, w);
+  f = f + e[7] * cross(w, v);  // Magnus
+  float p0 = e[8], p1 = e[9], p2 = e[10];
+  float pd = p0 * p0 * p0 * p0 * v.x * v.x + p1 * p1 * p1 * p1 * v.y * v.y + p2 * p2 * p2 * p2 * v.z * v.z;
+  float pn = (p0 * v.x) * (p0 * v.x) + (p1 * v.y) * (p1 * v.y) + (p2 * v.z) * (p2 * v.z);
+  const float kPi = 3.14159265358979f;
+  float A_proj = kPi * sqrtf(pd / fmaxf(1e-15f, pn));
+  V3 nrm = {p0 * p0 * v.x, p1 * p1 * v.y, p2 * p2 * v.z};
+  float speed = sqrtf(dot(v, v));
+  float cos_alpha = pn / fmaxf(1e-15f, speed * pd);
+  V3 circ = (e[11] * cos_alpha * A_proj) * cross(nrm, v);
+  f = f + cross(circ, v);  // Kutta
+  V3 mom = {w.x * (e[15] * e[19] + e[14] * (e[18] - e[19])), w.y * (e[15] * e[20] + e[14] * (e[18] - e[20])), w.z * (e[15] * e[21] + e[14] * (e[18] - e[21]))};
+  float drag_lin = e[16] + e[22] * speed * (A_proj * e[13] + e[14] * (e[12] - A_proj));
+  float drag_ang = e[17] + e[22] * sqrtf(dot(mom, mom));
+  t = t - drag_ang * w;
+  f = f - drag_lin * v;
+  t = e[0] * t; f = e[0] * f;
+  V3 tw = mv(R, t), fw = mv(R, f);
+  return mk6(tw + cross(dif, fw), fw);
+}
+
+// mj: getimpedance
+__device__ __forceinline__ float impedance(float dmin, float dmax, float width, float mid, float power, float pos, float margin) {
+  if (dmin == dmax || width <= 1e-15f) return 0.5f * (dmin + dmax);
+  float x = fabsf((pos - margin) / width);
+  if (x >= 1.f) return dmax;
+  if (x <= 0.f) return dmin;
+  float y;
+  if (power == 1.f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
+  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  return dmin + y * (dmax - dmin);
+}
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ unsigned long long env_rng(unsigned long long seed, unsigned long long env, unsigned long long episode, unsigned long long stream) {
+  return splitmix64(splitmix64(splitmix64(seed ^ 0xF1B0D7ULL) + env) + (episode << 2) + stream);
+}
+
+// ------------------------------------------------------------------------------------------------ per-wave context
+struct Ctx {
+  const DevModel &M;
+  Tile &T;
+  int lane;
+  int flags;
+  // per-dof registers
+  int d_link, d_kind, d_madr, d_depth, d_parent;
+  // per-link registers
+  int l_par, l_dofadr, l_dofnum, l_sub;
+  int lanc[8];  // ancestor chain of this lane's link, nearest first (-1 terminated)
+  V3 com;       // subtree CoM of the whole fly, root-relative
+  // outputs of stage 1 kept per dof lane
+  float f_smooth_nb;  // passive(spring+damper) - bias + fluid  (actuation is added in stage 2)
+  float qacc;         // constrained acceleration (mj: d->qacc)
+};
+
+#define SYNC() __syncthreads()
+
+// Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
+// mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
+__device__ void stage1(Ctx &c) {
+  const DevModel &M = c.M;
+  Tile &T = c.T;
+  const int lane = c.lane;
+  const bool is_link = lane < M.nlink, is_dof = lane < M.nv;
+
+  // ---- K1: link frame in its parent (joint rotations folded in) + hinge axes in the final link frame
+  if (is_link) {
+    Q4 q;
+    V3 p;
+    if (lane == 0) {
+      q = qnormalize(Q4{T.qpos[3], T.qpos[4], T.qpos[5], T.qpos[6]});
+      p = {0.f, 0.f, 0.f};
+    } else {
+      Q4 qr = {1.f, 0.f, 0.f, 0.f};
+      for (int j = c.l_dofnum - 1; j >= 0; j--) {
+        int d = c.l_dofadr + j;
+        V3 ax = ldv_lane(M.d_axis, d);
+        int qa = M.d_qadr[d];
+        V3 bax = qrot(qconj(qr), ax);
+        T.cdof[d][0] = bax.x; T.cdof[d][1] = bax.y; T.cdof[d][2] = bax.z;
+        qr = qmul(axis_angle(ax, T.qpos[qa] - M.qpos0[qa]), qr);
+      }
+      q = qmul(Q4{M.l_quat[lane], M.l_quat[kLanePad + lane], M.l_quat[2 * kLanePad + lane], M.l_quat[3 * kLanePad + lane]}, qr);
+      p = ldv_lane(M.l_pos, lane);
+    }
+    float *o = T.lT[lane];
+    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+  }
+  SYNC();
+  // ---- K2: compose up the ancestor chain (every lane walks its own chain; no per-level barrier)
+  V3 xp = {0.f, 0.f, 0.f}, xip = {0.f, 0.f, 0.f};
+  M3 xm = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, xim = xm;
+  float mass = 0.f;
+  if (is_link) {
+    const float *o = T.lT[lane];
+    V3 p = {o[0], o[1], o[2]};
+    Q4 q = {o[3], o[4], o[5], o[6]};
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      int a = c.lanc[it];
+      if (a >= 0) {
+        const float *oa = T.lT[a];
+        Q4 qa = {oa[3], oa[4], oa[5], oa[6]};
+        p = V3{oa[0], oa[1], oa[2]} + qrot(qa, p);
+        q = qmul(qa, q);
+      }
+    }
+    q = qnormalize(q);
+    xp = p;
+    xm = q2m(q);
+    mass = M.l_mass[lane];
+    xip = xp + mv(xm, ldv_lane(M.l_ipos, lane));
+    xim = mm(xm, ldm_lane(M.l_imat, lane));
+    T.xpos[lane][0] = xp.x; T.xpos[lane][1] = xp.y; T.xpos[lane][2] = xp.z;
+    float *xo = T.xmat[lane];
+    xo[0] = xm.m0; xo[1] = xm.m1; xo[2] = xm.m2; xo[3] = xm.m3; xo[4] = xm.m4; xo[5] = xm.m5; xo[6] = xm.m6; xo[7] = xm.m7; xo[8] = xm.m8;
+  }
+  // mj: mj_comPos - CoM of the whole tree (all lanes take part in the reduction)
+  {
+    float inv = 1.0f / M.total_mass;
+    c.com = {wave_sum(mass * xip.x) * inv, wave_sum(mass * xip.y) * inv, wave_sum(mass * xip.z) * inv};
+  }
+  I10 cin = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (is_link) {
+    cin = inert_com(ldv_lane(M.l_inertia, lane), xim, xip - c.com, mass);
+    st10(T.cinert[lane], cin);
+  }
+  SYNC();
+  // ---- dof axes in the com-centred world frame (mj: mju_dofCom)
+  S6 cd = zero6();
+  float qv = 0.f;
+  if (is_dof) {
+    qv = T.qvel[lane];
+    if (c.d_kind == 0) {
+      int k = lane;  // translational root dofs are dofs 0..2
+      cd = {0.f, 0.f, 0.f, k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f};
+    } else {
+      const float *xo = T.xmat[c.d_link];
+      V3 ax;
+      if (c.d_kind == 1) {
+        int k = lane - 3;
+        ax = {xo[k], xo[3 + k], xo[6 + k]};
+      } else {
+        V3 b = {T.cdof[lane][0], T.cdof[lane][1], T.cdof[lane][2]};
+        ax = mv(ldm(xo), b);
+      }
+      V3 off = c.com - V3{T.xpos[c.d_link][0], T.xpos[c.d_link][1], T.xpos[c.d_link][2]};
+      cd = mk6(ax, cross(ax, off));
+    }
+  }
+  SYNC();  // every lane has consumed its link-frame axis before cdof is overwritten
+  if (is_dof) st6(T.cdof[lane], cd);
+  SYNC();
+  // ---- V1: velocity increment contributed by each link's own dofs
+  if (is_link) {
+    S6 dv = zero6();
+    for (int j = 0; j < c.l_dofnum; j++) dv = dv + T.qvel[c.l_dofadr + j] * ld6(T.cdof[c.l_dofadr + j]);
+    st6(T.la[lane], dv);
+  }
+  SYNC();
+  // ---- V2: mj_comVel - link velocity = sum over the ancestor chain
+  S6 cvel = zero6();
+  if (is_link) {
+    cvel = ld6(T.la[lane]);
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      int a = c.lanc[it];
+      if (a >= 0) cvel = cvel + ld6(T.la[a]);
+    }
+    st6(T.lb[lane], cvel);
+  }
+  SYNC();
+  // ---- V3: cdof_dot = (velocity just before this dof) x cdof
+  S6 cdd = zero6();
+  if (is_dof) {
+    if (c.d_kind == 2) {
+      int b = c.d_link;
+      int pl = M.l_parent[b];
+      S6 cv = ld6(T.lb[pl]);
+      for (int e = M.l_dofadr[b]; e < lane; e++) cv = cv + T.qvel[e] * ld6(T.cdof[e]);
+      cdd = cross_motion(cv, cd);
+    } else if (c.d_kind == 1) {
+      S6 cv = {0.f, 0.f, 0.f, T.qvel[0], T.qvel[1], T.qvel[2]};  // free joint: after the 3 translations only
+      cdd = cross_motion(cv, cd);
+    }
+    st6(T.cdofd[lane], cdd);
+  }
+  SYNC();
+  // ---- A1: per-link sum of cdof_dot * qvel
+  if (is_link) {
+    S6 da = zero6();
+    for (int j = 0; j < c.l_dofnum; j++) da = da + T.qvel[c.l_dofadr + j] * ld6(T.cdofd[c.l_dofadr + j]);
+    st6(T.la[lane], da);
+  }
+  SYNC();
+  // ---- A2: mj_rne forward pass + mj_passive fluid forces, per link
+  S6 frc = zero6();
+  if (is_link) {
+    S6 cacc = ld6(T.la[lane]);
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      int a = c.lanc[it];
+      if (a >= 0) cacc = cacc + ld6(T.la[a]);
+    }
+    if (!(c.flags & FFE_NO_GRAVITY)) { cacc.l0 -= M.gx; cacc.l1 -= M.gy; cacc.l2 -= M.gz; }
+    frc = mul_inert(cin, cacc) + cross_force(cvel, mul_inert(cin, cvel));
+    int kind = (c.flags & FFE_NO_FLUID) ? 0 : M.l_reckind[lane];
+    if (kind == 1) frc = frc - box_fluid(M.l_reccoef, lane, ldv_lane(M.l_recpos, lane), ldm_lane(M.l_recmat, lane), xp, xm, cvel, c.com);
+    else if (kind == 2) frc = frc - ell_fluid(M.ell + 32 * M.l_recell[lane], ldv_lane(M.l_recpos, lane), ldm_lane(M.l_recmat, lane), xp, xm, cvel, c.com);
+  }
+  {
+    // bodies welded to the root link: one inertia-box record per lane, reduced across the wave
+    S6 w = zero6();
+    if (lane < M.nrootrec && !(c.flags & FFE_NO_FLUID)) {
+      V3 rp = {T.xpos[0][0], T.xpos[0][1], T.xpos[0][2]};
+      w = box_fluid(M.rr_coef, lane, ldv_lane(M.rr_pos, lane), ldm_lane(M.rr_mat, lane), rp, ldm(T.xmat[0]), ld6(T.lb[0]), c.com);
+    }
+    w = wave_sum6(w);
+    if (lane == 0) frc = frc - w;
+  }
+  if (is_link) st6(T.lc[lane], frc);
+  SYNC();
+  // ---- A3: subtree sums (links are in depth-first order, so a subtree is a contiguous range) for forces and
+  //          composite inertias (mj: mj_rne backward pass, mj_crb accumulation)
+  if (is_link) {
+    S6 fs = frc;
+    I10 cr = cin;
+    for (int k = lane + 1; k < lane + c.l_sub; k++) {
+      fs = fs + ld6(T.lc[k]);
+      cr = add10(cr, ld10(T.cinert[k]));
+    }
+    st6(T.la[lane], fs);
+    st10(T.crb[lane], cr);
+  }
+  SYNC();
+  // ---- joint space: bias projection, joint springs and dampers; crb * cdof
+  if (is_dof) {
+    float bias = dot6(cd, ld6(T.la[c.d_link]));
+    float f = -bias;
+    if (c.d_kind == 2) {
+      if (!(c.flags & FFE_NO_SPRING)) f -= M.d_stiff[lane] * (T.qpos[M.d_qadr[lane]] - M.d_sref[lane]);
+    }
+    if (!(c.flags & FFE_NO_DAMPER)) f -= M.d_damp[lane] * qv;
+    c.f_smooth_nb = f;
+    st6(T.buf[lane], mul_inert(ld10(T.crb[c.d_link]), cd));
+  }
+  SYNC();
+  // ---- mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs
+  for (int e = lane; e < M.nM; e += kWave) {
+    int i = M.m_row[e], j = M.m_col[e];
+    float v = dot6(ld6(T.cdof[j]), ld6(T.buf[i]));
+    if (i == j) v += M.d_arm[i];
+    T.M[e] = v;
+  }
+  SYNC();
+}
+
+// mj: mj_factorI on (M + diag(add)); rows are left unscaled and 1/D kept aside (T.dinv).
+__device__ void factor(Ctx &c, float add) {
+  const DevModel &M = c.M;
+  Tile &T = c.T;
+  const int lane = c.lane;
+  for (int e = lane; e < M.nM; e += kWave) T.LD[e] = T.M[e];
+  SYNC();
+  if (lane < M.nv) T.LD[c.d_madr] += add;
+  SYNC();
+  for (int k = M.nv - 1; k > 0; k--) {
+    const int base = M.tri_off[k], cnt = M.tri_off[k + 1] - base;
+    if (cnt == 0) continue;
+    const int mk = M.d_madr[k];
+    const float invD = 1.0f / T.LD[mk];
+    for (int p = lane; p < cnt; p += kWave) {
+      unsigned t = M.tri[base + p];
+      int tgt = t >> 16, s = (t >> 8) & 0xff, u = t & 0xff;
+      T.LD[tgt] -= T.LD[mk + s] * invD * T.LD[mk + u];
+    }
+    SYNC();
+  }
+  if (lane < M.nv) T.dinv[lane] = 1.0f / T.LD[c.d_madr];
+  SYNC();
+}
+
+// mj: mj_solveLD with the factor above.  `rhs` per dof lane in, solution per dof lane out.
+__device__ float solve(Ctx &c, float rhs) {
+  const DevModel &M = c.M;
+  Tile &T = c.T;
+  const int lane = c.lane;
+  const bool is_dof = lane < M.nv;
+  if (is_dof) T.x[lane] = rhs;
+  SYNC();
+  // x <- L^-T x : pivots from the leaves to the root, each scattering to its ancestors
+  for (int i = M.nv - 1; i > 0; i--) {
+    const int n = M.d_depth[i] - 1;
+    if (n == 0) continue;
+    const int mi = M.d_madr[i];
+    if (lane < n) {
+      int a = M.m_col[mi + 1 + lane];
+      T.x[a] -= T.LD[mi + 1 + lane] * T.dinv[i] * T.x[i];
+    }
+    SYNC();
+  }
+  // x <- D^-1 x ; x <- L^-1 x : level by level from the root, every deeper dof folding in one ancestor per level
+  float acc = 0.f, di = 0.f;
+  if (is_dof) { di = T.dinv[lane]; acc = T.x[lane] * di; }
+  SYNC();
+  for (int lvl = 1; lvl <= M.maxdepth; lvl++) {
+    if (is_dof && c.d_depth == lvl) T.x[lane] = acc;
+    SYNC();
+    if (is_dof && c.d_depth > lvl) {
+      int t = c.d_depth - lvl;
+      acc -= T.LD[c.d_madr + t] * di * T.x[M.m_col[c.d_madr + t]];
+    }
+  }
+  SYNC();
+  return acc;
+}
+
+struct StepOut {
+  V3 acc_sample;  // accelerometer reading of this substep (valid on every lane)
+};
+
+// Stage 2 = mj_fwdActuation, mj_fwdAcceleration, mj_fwdConstraint (joint limits), accelerometer, mj_Euler.
+// `ctrl_force` is the per-dof generalized actuator force, already assembled.
+__device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, double *rootpos, unsigned long long &lo_mask, unsigned long long &hi_mask, int &iters_out) {
+  const DevModel &M = c.M;
+  Tile &T = c.T;
+  const int lane = c.lane;
+  const bool is_dof = lane < M.nv;
+  const float h = M.h;
+  float f = is_dof ? c.f_smooth_nb + qfrc_act : 0.f;
+  float qp = 0.f, qv = 0.f;
+  if (is_dof) { qv = T.qvel[lane]; if (c.d_kind == 2) qp = T.qpos[M.d_qadr[lane]]; }
+
+  // ---- mj_instantiateLimit / mj_makeImpedance / mj_referenceConstraint for this lane's hinge
+  bool ex_lo = false, ex_hi = false;
+  float D_lo = 0.f, D_hi = 0.f, ar_lo = 0.f, ar_hi = 0.f;
+  if (is_dof && c.d_kind == 2 && M.d_limited[lane] && !(c.flags & FFE_NO_LIMIT)) {
+    float margin = M.d_margin[lane];
+    float dist_lo = qp - M.d_lo[lane], dist_hi = M.d_hi[lane] - qp;
+    float dmin = M.d_solimp[lane], dmax = M.d_solimp[kLanePad + lane], width = M.d_solimp[2 * kLanePad + lane],
+          mid = M.d_solimp[3 * kLanePad + lane], power = M.d_solimp[4 * kLanePad + lane];
+    float K = M.d_K[lane], B = M.d_B[lane], iw = M.d_invw[lane];
+    if (dist_lo < margin) {
+      ex_lo = true;
+      float imp = impedance(dmin, dmax, width, mid, power, dist_lo, margin);
+      D_lo = 1.0f / fmaxf(1e-15f, (1.f - imp) * iw / imp);
+      ar_lo = -B * qv - K * imp * (dist_lo - margin);
+    }
+    if (dist_hi < margin) {
+      ex_hi = true;
+      float imp = impedance(dmin, dmax, width, mid, power, dist_hi, margin);
+      D_hi = 1.0f / fmaxf(1e-15f, (1.f - imp) * iw / imp);
+      ar_hi = B * qv - K * imp * (dist_hi - margin);
+    }
+  }
+  const unsigned long long ex_any = __ballot(ex_lo || ex_hi);
+  // Primal active-set Newton on  1/2 (a-a_s)'M(a-a_s) + sum 1/2 D min(0, J a - aref)^2 : with hinge limits the Hessian
+  // is M + diag(D_active), i.e. the same sparse factorisation with a different diagonal; with no limit instantiated it
+  // degenerates to qacc = M^-1 qfrc_smooth.  The implicit-damping Euler solve (M + h B) reuses the same code as a final
+  // pass of the loop so that factor/solve are instantiated once.
+  bool act_lo = ex_lo, act_hi = ex_hi;  // first guess: an instantiated limit is active
+  float a = 0.f, ae = 0.f, fc = 0.f;
+  int iters = 0;
+  bool euler_phase = false;
+  const bool want_euler = integrate && !(c.flags & FFE_NO_DAMPER);
+#pragma unroll 1
+  for (int it = 0; it < 10; it++) {
+    float add, rhs;
+    if (!euler_phase) {
+      add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
+      rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
+    } else {
+      add = is_dof ? h * M.d_damp[lane] : 0.f;
+      rhs = f + fc;
+    }
+    factor(c, add);
+    float x = solve(c, rhs);
+    if (euler_phase) { ae = x; break; }
+    a = x;
+    iters++;
+    bool n_lo = ex_lo && (a - ar_lo < 0.f);
+    bool n_hi = ex_hi && (-a - ar_hi < 0.f);
+    bool changed = (n_lo != act_lo) || (n_hi != act_hi);
+    act_lo = n_lo; act_hi = n_hi;
+    if (ex_any == 0ULL || __ballot(changed) == 0ULL || it >= 6) {
+      if (act_lo) fc += D_lo * (ar_lo - a);
+      if (act_hi) fc -= D_hi * (ar_hi + a);
+      if (!want_euler) { ae = a; break; }
+      euler_phase = true;
+    }
+  }
+  lo_mask = __ballot(act_lo);
+  hi_mask = __ballot(act_hi);
+  iters_out = ex_any ? iters : 0;
+  c.qacc = a;
+  // ---- accelerometer (mj: mj_rnePostConstraint + mj_objectAcceleration at the thorax site, which sits at the
+  //      root-body origin): R^T (a_origin - g) with a_origin the free joint's linear acceleration
+  V3 accel;
+  {
+    V3 ao = {__shfl(a, 0), __shfl(a, 1), __shfl(a, 2)};
+    if (!(c.flags & FFE_NO_GRAVITY)) { ao.x -= M.gx; ao.y -= M.gy; ao.z -= M.gz; }
+    accel = mtv(ldm(T.xmat[0]), ao);
+  }
+  if (!integrate) return accel;
+  // ---- mj_Euler: semi-implicit update with the damping-implicit acceleration
+  if (is_dof) {
+    float nv_ = qv + h * ae;
+    T.qvel[lane] = nv_;
+    if (c.d_kind == 2) T.qpos[M.d_qadr[lane]] = qp + h * nv_;
+  }
+  SYNC();
+  if (lane == 0) {
+    // free joint: position in float64, orientation by mju_quatIntegrate with the body-frame angular velocity
+    rootpos[0] += (double)h * (double)T.qvel[0];
+    rootpos[1] += (double)h * (double)T.qvel[1];
+    rootpos[2] += (double)h * (double)T.qvel[2];
+    V3 w = {T.qvel[3], T.qvel[4], T.qvel[5]};
+    float n = sqrtf(dot(w, w));
+    Q4 q = qnormalize(Q4{T.qpos[3], T.qpos[4], T.qpos[5], T.qpos[6]});
+    if (n >= 1e-15f) {
+      V3 ax = (1.0f / n) * w;
+      q = qnormalize(qmul(q, axis_angle(ax, n * h)));
+    }
+    T.qpos[3] = q.w; T.qpos[4] = q.x; T.qpos[5] = q.y; T.qpos[6] = q.z;
+  }
+  SYNC();
+  return accel;
+}
+
+// mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.
+__device__ float actuation(Ctx &c, const float *ctrl_lds) {
+  const DevModel &M = c.M;
+  Tile &T = c.T;
+  const int lane = c.lane;
+  if (c.flags & FFE_NO_ACTUATION) return 0.f;
+  if (lane < M.nu) {
+    float ctrl = ctrl_lds[lane];
+    if (M.a_cl[lane]) ctrl = fminf(fmaxf(ctrl, M.a_clo[lane]), M.a_chi[lane]);
+    float len = 0.f, vel = 0.f;
+    if (M.a_trn[lane] == 0) { len = T.qpos[M.a_qadr[lane]]; vel = T.qvel[M.a_dof[lane]]; }
+    else for (int w = M.a_wrap_off[lane]; w < M.a_wrap_off[lane + 1]; w++) { len += M.w_coef[w] * T.qpos[M.w_qadr[w]]; vel += M.w_coef[w] * T.qvel[M.w_dof[w]]; }
+    float force = M.a_gain[lane] * ctrl + M.a_b0[lane] + M.a_b1[lane] * len + M.a_b2[lane] * vel;
+    if (M.a_fl[lane]) force = fminf(fmaxf(force, M.a_flo[lane]), M.a_fhi[lane]);
+    T.frc[lane] = force;
+  }
+  SYNC();
+  float q = 0.f;
+  if (lane < M.nv) {
+    int a0 = M.d_act_id[lane], a1 = M.d_act_id[kLanePad + lane];
+    if (a0 >= 0) q += M.d_act_coef[lane] * T.frc[a0];
+    if (a1 >= 0) q += M.d_act_coef[kLanePad + lane] * T.frc[a1];
+  }
+  SYNC();
+  return q;
+}
+
+// ------------------------------------------------------------------------------------------------ task helpers
+// argmin_i |table[i] - x| with numpy's first-minimum tie-break, across the wave (float64, bit-compatible
+// with the reference's np.argmin(np.abs(...)) on the same tables; ref: pattern_generators.py:148,179,186)
+__device__ int wave_argmin_absdiff(const double *tab, int n, double x, int lane) {
+  double bv = 1e300;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < n; i += kWave) {
+    double v = fabs(x - tab[i]);
+    if (v < bv) { bv = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(bv, o);
+    int oi = __shfl_xor(bi, o);
+    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  return bi;
+}
+
+struct ObsLayout { int acc, gyro, jpos, jvel, vel, zaxis, rdisp, rquat; };
+__device__ __forceinline__ ObsLayout obs_layout(int nj, int nref) {
+  ObsLayout o;
+  o.acc = 0; o.gyro = 3; o.jpos = 6; o.jvel = 6 + nj; o.vel = 6 + 2 * nj; o.zaxis = o.vel + 3; o.rdisp = o.zaxis + 3; o.rquat = o.rdisp + 3 * nref;
+  return o;
+}
+
+// Observation assembly (ref: fruitfly.py:532-708 enabled set per tasks/base.py:167-168 + flight_imitation.py:84-85;
+// ref_displacement / ref_root_quat: tasks/base.py:237-261).  Returns |ref_displacement[0]| and ref_root_quat[0].
+__device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, const double *rootpos, int traj_idx, int step_counter,
+                          float &com_dist, Q4 &rq0) {
+  const DevModel &M = c.M;
+  Tile &T = c.T;
+  const int lane = c.lane;
+  const int nref = K.future_steps + 1;
+  const ObsLayout L = obs_layout(M.nobsj, nref);
+  if (lane == 0) {
+    obs[L.acc] = s_acc.x; obs[L.acc + 1] = s_acc.y; obs[L.acc + 2] = s_acc.z;
+    obs[L.gyro] = s_gyro.x; obs[L.gyro + 1] = s_gyro.y; obs[L.gyro + 2] = s_gyro.z;
+    obs[L.vel] = s_vel.x; obs[L.vel + 1] = s_vel.y; obs[L.vel + 2] = s_vel.z;
+    obs[L.zaxis] = T.xmat[0][6]; obs[L.zaxis + 1] = T.xmat[0][7]; obs[L.zaxis + 2] = T.xmat[0][8];
+  }
+  if (lane < M.nobsj) {
+    obs[L.jpos + lane] = T.qpos[M.obsj_qadr[lane]];
+    obs[L.jvel + lane] = T.qvel[M.obsj_dof[lane]];
+  }
+  float cd = 0.f;
+  Q4 r0 = {1.f, 0.f, 0.f, 0.f};
+  if (lane < nref) {
+    const double *r = K.ref_qpos + ((size_t)traj_idx * K.traj_len + step_counter + lane) * 7;
+    V3 dv = {(float)(r[0] - rootpos[0]), (float)(r[1] - rootpos[1]), (float)(r[2] - rootpos[2])};
+    V3 e = mtv(ldm(T.xmat[0]), dv);
+    obs[L.rdisp + 3 * lane] = e.x; obs[L.rdisp + 3 * lane + 1] = e.y; obs[L.rdisp + 3 * lane + 2] = e.z;
+    Q4 fq = {T.qpos[3], T.qpos[4], T.qpos[5], T.qpos[6]};
+    Q4 dq = qmul(quat_recip(fq), Q4{(float)r[3], (float)r[4], (float)r[5], (float)r[6]});
+    obs[L.rquat + 4 * lane] = dq.w; obs[L.rquat + 4 * lane + 1] = dq.x; obs[L.rquat + 4 * lane + 2] = dq.y; obs[L.rquat + 4 * lane + 3] = dq.z;
+    if (lane == 0) { cd = sqrtf(dot(e, e)); r0 = dq; }
+  }
+  com_dist = __shfl(cd, 0);
+  rq0 = {__shfl(r0.w, 0), __shfl(r0.x, 0), __shfl(r0.y, 0), __shfl(r0.z, 0)};
+}
+
+__device__ __forceinline__ void load_lane_consts(Ctx &c) {
+  const DevModel &M = c.M;
+  const int lane = c.lane;
+  c.d_link = M.d_link[lane]; c.d_kind = M.d_kind[lane]; c.d_madr = M.d_madr[lane]; c.d_depth = M.d_depth[lane]; c.d_parent = M.d_parent[lane];
+  c.l_par = M.l_parent[lane]; c.l_dofadr = M.l_dofadr[lane]; c.l_dofnum = M.l_dofnum[lane]; c.l_sub = M.l_sub[lane];
+  int a = lane < M.nlink ? c.l_par : -1;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    c.lanc[it] = a;
+    a = a >= 0 ? M.l_parent[a] : -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ the step kernel
+// One launch = one dm_env step of every env.  mode: 0 = step (auto-reset envs that ended), 1 = reset all.
+__global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *__restrict__ Mp, const TaskDev *__restrict__ Kp, EnvState *__restrict__ states, const float *__restrict__ act,
+                                                              float *__restrict__ obs_out, float *__restrict__ reward_out,
+                                                              float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode) {
+  __shared__ Tile T;
+  const DevModel &M = *Mp;
+  const TaskDev &K = *Kp;
+  const int env = blockIdx.x;
+  if (env >= batch) return;
+  const int lane = threadIdx.x;
+  EnvState &S = states[env];
+  Ctx c{M, T, lane, K.flags};
+  load_lane_consts(c);
+  float *obs = obs_out + (size_t)env * K.obs_dim;
+  const int nsub = M.nsub;
+
+  double rootpos[3] = {S.rootpos[0], S.rootpos[1], S.rootpos[2]};
+  unsigned long long lo_mask = S.lo_mask, hi_mask = S.hi_mask;
+  int wb_step = S.wb_step, wb_idx = S.wb_freq_idx, step_counter = S.step_counter, traj_idx = S.traj_idx;
+  double wb_cf = S.wb_ctrl_freq;
+  const bool do_reset = (mode == 1) || (S.needs_reset != 0);
+  int iters = 0;
+
+  // ---- prepare: either start a new episode or load the env's state and run the task pre-step
+  unsigned long long episode = S.episode;
+  float ctrl_reg = 0.f;
+  double gpos[3] = {0, 0, 0}, gvel[3] = {0, 0, 0}, gq[4] = {1, 0, 0, 0}, gw[3] = {0, 0, 0};
+  if (do_reset) {
+    // ref: flight_imitation.py:93-147 + composer reset
+    double phase;
+    if (S.forced_traj >= 0) { traj_idx = S.forced_traj; phase = S.forced_phase; }
+    else {
+      traj_idx = (int)(env_rng(K.seed, K.env_id_base + env, episode, 0) % (unsigned long long)K.ntraj);
+      phase = (double)(env_rng(K.seed, K.env_id_base + env, episode, 1) >> 11) * (1.0 / 9007199254740992.0);
+    }
+    episode++;
+    step_counter = 0;
+    // ref: pattern_generators.py:121-157 reset
+    wb_cf = K.base_freq;
+    wb_idx = wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane);
+    int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
+    wb_step = wave_argmin_absdiff(K.phase + off, len, phase, lane);
+    const int nxt = wb_step + 1 < len ? wb_step + 1 : 0;  // the reference reads [step+1] unguarded
+    const double *rq = K.ref_qpos + (size_t)traj_idx * K.traj_len * 7, *rv = K.ref_qvel + (size_t)traj_idx * K.traj_len * 6;
+    if (lane < kMaxDof + 4) { T.qpos[lane] = lane < M.nq ? M.qpos0[lane] : 0.f; T.qvel[lane] = 0.f; }
+    SYNC();
+    if (lane == 0) {
+      T.qpos[3] = (float)rq[3]; T.qpos[4] = (float)rq[4]; T.qpos[5] = (float)rq[5]; T.qpos[6] = (float)rq[6];
+      T.qvel[0] = (float)rv[0]; T.qvel[1] = (float)rv[1]; T.qvel[2] = (float)rv[2];  // initialize_qvel: linear only
+    }
+    rootpos[0] = rq[0]; rootpos[1] = rq[1]; rootpos[2] = rq[2];
+    for (int k = 0; k < 3; k++) gpos[k] = rq[k];
+    for (int k = 0; k < 4; k++) gq[k] = rq[3 + k];
+    if (lane < M.nwing) {
+      float q0 = K.traj[(size_t)(off + wb_step) * 6 + lane], q1 = K.traj[(size_t)(off + nxt) * 6 + lane];
+      T.qpos[M.wing_qadr[lane]] = q0;
+      T.qvel[M.wing_dof[lane]] = (float)(((double)q1 - (double)q0) / K.dt_ctrl);
+    }
+    lo_mask = hi_mask = 0ULL;
+    SYNC();
+  } else {
+    if (lane < kMaxDof + 4) { T.qpos[lane] = S.qpos[lane]; T.qvel[lane] = S.qvel[lane]; }
+    SYNC();
+    // before_step (ref: flight_imitation.py:149-167, base.py:190-193, fruitfly.py:480-492)
+    const float *a_in = act + (size_t)env * M.naction;
+    float act_user = a_in[M.user_action];
+    if (!(act_user == act_user)) act_user = 0.f;
+    double cmd = K.base_freq * (1.0 + K.rel_range * (double)act_user);
+    {
+      // ref: pattern_generators.py:159-191 step
+      int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
+      wb_step = (wb_step + 1) % len;
+      wb_cf = wb_cf * K.rate + cmd * (1.0 - K.rate);
+      int idx_new = wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane);
+      if (idx_new != wb_idx) {
+        double cur = K.phase_frac[off + wb_step];
+        int noff = K.tab_off[idx_new], nlen = K.tab_off[idx_new + 1] - noff;
+        wb_step = wave_argmin_absdiff(K.phase_frac + noff, nlen, cur, lane);
+        wb_idx = idx_new;
+      }
+    }
+    if (lane < M.nu) {
+      int ai = M.a_action[lane];
+      float v = ai >= 0 ? a_in[ai] : 0.f;
+      if (!(v == v)) v = 0.f;
+      T.x[lane] = v;
+    }
+    SYNC();
+    if (lane < M.nwing) {
+      // action[wings] += target - qpos[wing]; the wing actuators are the ctrl slots fed by those action entries
+      float tgt = K.traj[(size_t)(K.tab_off[wb_idx] + wb_step) * 6 + lane];
+      float add = tgt - T.qpos[M.wing_qadr[lane]];
+      for (int u = 0; u < M.nu; u++) if (M.a_action[u] == M.wing_action[lane]) T.x[u] += add;
+    }
+    SYNC();
+    ctrl_reg = lane < M.nu ? T.x[lane] : 0.f;
+    SYNC();
+    const double *rq = K.ref_qpos + ((size_t)traj_idx * K.traj_len + step_counter) * 7, *rv = K.ref_qvel + ((size_t)traj_idx * K.traj_len + step_counter) * 6;
+    for (int k = 0; k < 3; k++) { gpos[k] = rq[k]; gvel[k] = rv[k]; gw[k] = rv[3 + k]; }
+    for (int k = 0; k < 4; k++) gq[k] = rq[3 + k];
+    step_counter++;
+  }
+  // ---- physics.  dm_control's legacy step is mj_step2 then mj_step1, so the position/velocity stage is evaluated
+  //      once up front and again after every integration; buffered sensors take one sample per substep.  A reset
+  //      is the same pipeline run once without actuation and without integrating (mj_forward).
+  V3 s_acc = {0.f, 0.f, 0.f}, s_gyro = {0.f, 0.f, 0.f}, s_vel = {0.f, 0.f, 0.f};
+  const int nst = do_reset ? 1 : nsub;
+#pragma unroll 1
+  for (int s = 0; s <= nst; s++) {
+    stage1(c);
+    if (do_reset || s > 0) {
+      s_gyro = s_gyro + V3{T.qvel[3], T.qvel[4], T.qvel[5]};
+      s_vel = s_vel + mtv(ldm(T.xmat[0]), V3{T.qvel[0], T.qvel[1], T.qvel[2]});
+    }
+    if (s == nst) break;
+    float qa = 0.f;
+    if (!do_reset) {
+      if (lane < M.nu) T.frc[lane] = ctrl_reg;
+      SYNC();
+      qa = actuation(c, T.frc);
+    }
+    int it = 0;
+    s_acc = s_acc + stage2(c, qa, !do_reset, rootpos, lo_mask, hi_mask, it);
+    iters += it;
+    if (do_reset) break;
+    rootpos[0] = __shfl(rootpos[0], 0); rootpos[1] = __shfl(rootpos[1], 0); rootpos[2] = __shfl(rootpos[2], 0);
+    // ghost: armature-1 free body coasting at the reference velocity (closed form, float64)
+    gvel[2] += (double)M.h * K.ghost_accel_z;
+    for (int k = 0; k < 3; k++) gpos[k] += (double)M.h * gvel[k];
+    double n = sqrt(gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2]);
+    double qn = sqrt(gq[0] * gq[0] + gq[1] * gq[1] + gq[2] * gq[2] + gq[3] * gq[3]);
+    for (int k = 0; k < 4; k++) gq[k] /= qn;
+    if (n >= 1e-15) {
+      double sh, ch;
+      sincos(0.5 * n * (double)M.h, &sh, &ch);
+      double ax = gw[0] / n * sh, ay = gw[1] / n * sh, az = gw[2] / n * sh;
+      double w = gq[0] * ch - gq[1] * ax - gq[2] * ay - gq[3] * az, x = gq[0] * ax + gq[1] * ch + gq[2] * az - gq[3] * ay,
+             y = gq[0] * ay - gq[1] * az + gq[2] * ch + gq[3] * ax, z = gq[0] * az + gq[1] * ay - gq[2] * ax + gq[3] * ch;
+      double m = sqrt(w * w + x * x + y * y + z * z);
+      gq[0] = w / m; gq[1] = x / m; gq[2] = y / m; gq[3] = z / m;
+    }
+  }
+  const float inv = (do_reset && K.pad_first_obs) ? 1.f : 1.f / (float)nsub;
+  float cdist;
+  Q4 rq0;
+  write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, rootpos, traj_idx, step_counter, cdist, rq0);
+  if (do_reset) {
+    if (lane == 0) { reward_out[env] = 0.f; discount_out[env] = 1.f; step_type_out[env] = FFE_STEP_FIRST; S.needs_reset = 0; S.forced_traj = -1; }
+  } else {
+    // ---- check_termination (ref: flight_imitation.py:198-209, base.py:214-217); qacc is the last substep's
+    float qn2 = wave_sum(lane < M.nv ? c.qacc * c.qacc : 0.f);
+    float height = (float)rootpos[2];
+    int lim = K.traj_len < K.time_limit_steps ? K.traj_len : K.time_limit_steps;
+    int traj_timesteps = lim - (K.future_steps + 1);
+    bool reached_end = (step_counter == traj_timesteps);
+    bool bad = !(qn2 == qn2) || !(sqrtf(qn2) <= 1e14f);
+    bool term = height < 0.2f || cdist > (float)K.terminal_com_dist || reached_end || bad;
+    // ---- reward (ref: flight_imitation.py:169-196): ghost CoM vs walker CoM, and root orientation error
+    if (lane == 0) {
+      const double ox = -0.03697732, oy = 0.00029205, oz = -0.0142447;  // ref: task_utils.py:188
+      double w = gq[0], x = gq[1], y = gq[2], z = gq[3];
+      double n2 = w * w + x * x + y * y + z * z;
+      double gx = gpos[0] + ((w * w + x * x - y * y - z * z) * ox + 2 * (x * y - w * z) * oy + 2 * (x * z + w * y) * oz) / n2;
+      double gy = gpos[1] + (2 * (x * y + w * z) * ox + (w * w - x * x + y * y - z * z) * oy + 2 * (y * z - w * x) * oz) / n2;
+      double gz = gpos[2] + (2 * (x * z - w * y) * ox + 2 * (y * z + w * x) * oy + (w * w - x * x - y * y + z * z) * oz) / n2;
+      double dx = gx - (rootpos[0] + (double)c.com.x), dy = gy - (rootpos[1] + (double)c.com.y), dz = gz - (rootpos[2] + (double)c.com.z);
+      float r1 = fmaxf(0.f, 1.f - (float)sqrt(dx * dx + dy * dy + dz * dz) / 0.4f);
+      float r2 = fmaxf(0.f, 1.f - quat_dist_short_arc(Q4{1.f, 0.f, 0.f, 0.f}, rq0) / 3.14159265358979f);
+      float reward = r1 * r2;
+      float discount = (term && !reached_end) ? 0.f : 1.f;
+      if (bad || !(reward == reward)) { reward = 0.f; discount = 0.f; }
+      bool time_up = step_counter >= K.time_limit_steps;
+      reward_out[env] = reward; discount_out[env] = discount;
+      step_type_out[env] = (term || time_up) ? FFE_STEP_LAST : FFE_STEP_MID;
+      S.needs_reset = (term || time_up) ? 1 : 0;
+    }
+  }
+  if (lane == 0) {
+    for (int k = 0; k < 3; k++) S.ghost[k] = gpos[k];
+    for (int k = 0; k < 4; k++) S.ghost[3 + k] = gq[k];
+    S.episode = episode;
+  }
+  // ---- store state
+  if (lane < kMaxDof + 4) { S.qpos[lane] = T.qpos[lane]; S.qvel[lane] = T.qvel[lane]; }
+  if (lane == 0) {
+    S.rootpos[0] = rootpos[0]; S.rootpos[1] = rootpos[1]; S.rootpos[2] = rootpos[2];
+    S.wb_ctrl_freq = wb_cf; S.wb_step = wb_step; S.wb_freq_idx = wb_idx; S.step_counter = step_counter; S.traj_idx = traj_idx;
+    S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.solver_iters = iters;
+    S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
+  }
+}
+
+__global__ void init_states_kernel(EnvState *states, int batch) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  EnvState z;
+  memset(&z, 0, sizeof(z));
+  z.needs_reset = 1; z.forced_traj = -1;
+  states[i] = z;
+}
+__global__ void get_state_kernel(const EnvState *states, double *qpos, double *qvel, int batch, int nq, int nv) {
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= batch) return;
+  const EnvState &S = states[env];
+  if (lane < nq) qpos[(size_t)env * nq + lane] = lane < 3 ? S.rootpos[lane] : (double)S.qpos[lane];
+  if (lane < nv) qvel[(size_t)env * nv + lane] = (double)S.qvel[lane];
+}
+__global__ void set_state_kernel(EnvState *states, const double *qpos, const double *qvel, int batch, int nq, int nv) {
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= batch) return;
+  EnvState &S = states[env];
+  if (lane < nq) { if (lane < 3) S.rootpos[lane] = qpos[(size_t)env * nq + lane]; else S.qpos[lane] = (float)qpos[(size_t)env * nq + lane]; }
+  if (lane < nv) S.qvel[lane] = (float)qvel[(size_t)env * nv + lane];
+  if (lane == 0) { S.lo_mask = 0; S.hi_mask = 0; }
+}
+__global__ void get_task_state_kernel(const EnvState *states, int *ints, double *reals, int batch) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  const EnvState &S = states[i];
+  int *o = ints + (size_t)i * 8;
+  o[0] = S.wb_step; o[1] = S.wb_freq_idx; o[2] = S.step_counter; o[3] = S.traj_idx; o[4] = S.needs_reset; o[5] = S.nactive; o[6] = S.solver_iters; o[7] = 0;
+  double *r = reals + (size_t)i * 8;
+  r[0] = S.wb_ctrl_freq;
+  for (int k = 0; k < 7; k++) r[1 + k] = S.ghost[k];
+}
+__global__ void force_next_kernel(EnvState *states, const int *traj, const double *phase, int batch) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  states[i].forced_traj = traj[i];
+  states[i].forced_phase = phase[i];
+}
+__global__ void test_quat_kernel(int op, const float *a, const float *b, float *out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Q4 qa = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]}, qb = {b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]};
+  Q4 r = {0, 0, 0, 0};
+  if (op == 0) r = qmul(qa, qb);
+  else if (op == 1) r = quat_recip(qa);
+  else if (op == 2) { V3 v = rotate_vec_with_quat(V3{qa.w, qa.x, qa.y}, qb); r = {v.x, v.y, v.z, 0.f}; }
+  else if (op == 3) r = {quat_dist_short_arc(qa, qb), 0.f, 0.f, 0.f};
+  else if (op == 4) r = qmul(quat_recip(qa), qb);
+  out[4 * i] = r.w; out[4 * i + 1] = r.x; out[4 * i + 2] = r.y; out[4 * i + 3] = r.z;
+}
+
+}  // namespace ffe
+
+// ================================================================================================ C ABI
+using namespace ffe;
+
+struct ffe_env {
+  int device = 0, batch = 0;
+  DevModel dm{};
+  TaskDev task{};
+  DevModel *dm_dev = nullptr;
+  TaskDev *task_dev = nullptr;
+  HostModel host;
+  EnvState *states = nullptr;
+  unsigned char *arena = nullptr;
+  std::vector<void *> allocs;
+  std::string err;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static thread_local std::string g_err;
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+template <typename T>
+static T *upload(ffe_env *h, const T *src, size_t n) {
+  T *p = nullptr;
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T)));
+  h->allocs.push_back(p);
+  if (n) HIP_OK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return p;
+}
+
+extern "C" {
+
+const char *ffe_version(void) { return "flybody_amd 0.1 (gfx950, wave-per-env)"; }
+const char *ffe_last_error(ffe_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight_task *task, int batch, int device, uint64_t seed,
+                      uint64_t env_id_base, ffe_handle *out) {
+  if (!out) return -1;
+  *out = nullptr;
+  std::unique_ptr<ffe_env> h(new ffe_env());
+  try {
+    if (!model_blob || !task || batch <= 0) throw std::runtime_error("ffe_create_flight: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw std::runtime_error("no HIP device: the MI355X path has no CPU fallback");
+    HIP_OK(hipSetDevice(device));
+    Blob blob(model_blob, blob_size);
+    h->host = build_host_model(blob);
+    h->device = device; h->batch = batch;
+    h->arena = upload(h.get(), h->host.arena.data(), h->host.arena.size());
+    h->host.fixup(h->dm, h->arena);
+    const ffe_flight_task &t = *task;
+    if (t.wb_nfreq <= 0 || !t.wb_beat_freqs || !t.wb_tab_off || !t.wb_traj || !t.wb_phase || t.ntraj <= 0 || t.traj_len <= 0 || !t.ref_qpos || !t.ref_qvel)
+      throw std::runtime_error("ffe_create_flight: incomplete task tables");
+    if (t.future_steps + 1 > kMaxFuture) throw std::runtime_error("future_steps too large");
+    if (t.traj_len < t.future_steps + 2) throw std::runtime_error("trajectories too short");
+    if (h->dm.user_action < 0 || h->dm.nwing != 6) throw std::runtime_error("model is not the flight model");
+    h->dm.nsub = (int)llround(t.wb_dt_ctrl / (double)blob.get("opt").f(0));
+    const int rows = t.wb_tab_off[t.wb_nfreq];
+    std::vector<double> frac(rows);
+    std::vector<float> trajf((size_t)rows * 6);
+    for (int i = 0; i < rows; i++) frac[i] = std::fmod(t.wb_phase[i], 1.0);
+    for (size_t i = 0; i < trajf.size(); i++) trajf[i] = (float)t.wb_traj[i];
+    TaskDev &K = h->task;
+    K.nfreq = t.wb_nfreq; K.ntraj = t.ntraj; K.traj_len = t.traj_len; K.future_steps = t.future_steps; K.time_limit_steps = t.time_limit_steps;
+    K.pad_first_obs = t.pad_first_obs; K.flags = t.physics_flags;
+    K.base_freq = t.wb_base_freq; K.rel_range = t.wb_rel_range; K.rate = t.wb_rate; K.dt_ctrl = t.wb_dt_ctrl;
+    K.terminal_com_dist = t.terminal_com_dist; K.ghost_accel_z = t.ghost_accel_z;
+    K.beat_freqs = upload(h.get(), t.wb_beat_freqs, (size_t)t.wb_nfreq);
+    K.tab_off = upload(h.get(), t.wb_tab_off, (size_t)t.wb_nfreq + 1);
+    K.phase = upload(h.get(), t.wb_phase, (size_t)rows);
+    K.phase_frac = upload(h.get(), frac.data(), frac.size());
+    K.traj = upload(h.get(), trajf.data(), trajf.size());
+    K.ref_qpos = upload(h.get(), t.ref_qpos, (size_t)t.ntraj * t.traj_len * 7);
+    K.ref_qvel = upload(h.get(), t.ref_qvel, (size_t)t.ntraj * t.traj_len * 6);
+    K.seed = seed; K.env_id_base = env_id_base;
+    K.obs_dim = 12 + 2 * h->dm.nobsj + 7 * (t.future_steps + 1);
+    h->host.nobs = K.obs_dim;
+    h->dm_dev = upload(h.get(), &h->dm, 1);
+    h->task_dev = upload(h.get(), &h->task, 1);
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&h->states), sizeof(EnvState) * (size_t)batch));
+    h->allocs.push_back(h->states);
+    hipLaunchKernelGGL(init_states_kernel, dim3((batch + 255) / 256), dim3(256), 0, 0, h->states, batch);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipEventCreate(&h->ev0));
+    HIP_OK(hipEventCreate(&h->ev1));
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    for (void *p : h->allocs) (void)hipFree(p);
+    return -1;
+  }
+  *out = h.release();
+  return 0;
+}
+
+int ffe_destroy(ffe_handle h) {
+  if (!h) return -1;
+  (void)hipSetDevice(h->device);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return 0;
+}
+
+int ffe_spec(ffe_handle h, ffe_spec_t *s) {
+  if (!h || !s) return -1;
+  const DevModel &M = h->dm;
+  const int nref = h->task.future_steps + 1, nj = M.nobsj;
+  s->batch = h->batch; s->nq = M.nq; s->nv = M.nv; s->nu = M.nu; s->action_dim = M.naction; s->obs_dim = h->task.obs_dim; s->nsub = M.nsub;
+  s->physics_timestep = (double)M.h; s->control_timestep = h->task.dt_ctrl;
+  s->off_accelerometer = 0; s->off_gyro = 3; s->off_joints_pos = 6; s->off_joints_vel = 6 + nj; s->off_velocimeter = 6 + 2 * nj;
+  s->off_world_zaxis = 9 + 2 * nj; s->off_ref_displacement = 12 + 2 * nj; s->off_ref_root_quat = 12 + 2 * nj + 3 * nref;
+  s->n_obs_joints = nj; s->n_ref = nref;
+  return 0;
+}
+
+int ffe_action_bounds(ffe_handle h, float *mn, float *mx) {
+  if (!h || !mn || !mx) return -1;
+  std::memcpy(mn, h->host.action_min.data(), h->host.action_min.size() * sizeof(float));
+  std::memcpy(mx, h->host.action_max.data(), h->host.action_max.size() * sizeof(float));
+  return 0;
+}
+
+static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode) {
+  if (!h) return -1;
+  if (!obs || !rew || !disc || !st || (mode == 0 && !act)) { h->err = "null device buffer"; return -1; }
+  hipLaunchKernelGGL(flight_step_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->dm_dev, h->task_dev, h->states, act, obs, rew,
+                     disc, st, h->batch, mode);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
+  return 0;
+}
+
+int ffe_reset(ffe_handle h, float *obs, float *rew, float *disc, int32_t *st, void *stream) { return launch_step(h, nullptr, obs, rew, disc, st, stream, 1); }
+int ffe_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream) {
+  return launch_step(h, act, obs, rew, disc, st, stream, 0);
+}
+
+int ffe_force_next_episode(ffe_handle h, const int32_t *traj, const double *phase) {
+  if (!h || !traj || !phase) return -1;
+  try {
+    int *dt = nullptr; double *dp = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&dt), sizeof(int) * h->batch));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&dp), sizeof(double) * h->batch));
+    HIP_OK(hipMemcpy(dt, traj, sizeof(int) * h->batch, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dp, phase, sizeof(double) * h->batch, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(force_next_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, 0, h->states, dt, dp, h->batch);
+    HIP_OK(hipDeviceSynchronize());
+    (void)hipFree(dt); (void)hipFree(dp);
+  } catch (const std::exception &e) { h->err = e.what(); return -1; }
+  return 0;
+}
+
+int ffe_get_state(ffe_handle h, double *qpos, double *qvel, void *stream) {
+  if (!h || !qpos || !qvel) return -1;
+  hipLaunchKernelGGL(get_state_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->states, qpos, qvel, h->batch, h->dm.nq, h->dm.nv);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int ffe_set_state(ffe_handle h, const double *qpos, const double *qvel, void *stream) {
+  if (!h || !qpos || !qvel) return -1;
+  hipLaunchKernelGGL(set_state_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->states, qpos, qvel, h->batch, h->dm.nq, h->dm.nv);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int ffe_get_task_state(ffe_handle h, int32_t *ints, double *reals, void *stream) {
+  if (!h || !ints || !reals) return -1;
+  hipLaunchKernelGGL(get_task_state_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), h->states, ints, reals, h->batch);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ffe_time_steps(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream, float *ms) {
+  if (!h || !ms || iters <= 0) return -1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipEventRecord(h->ev0, s) != hipSuccess) return -2;
+  for (int i = 0; i < iters; i++) {
+    int rc = launch_step(h, act, obs, rew, disc, st, stream, 0);
+    if (rc) return rc;
+  }
+  if (hipEventRecord(h->ev1, s) != hipSuccess) return -2;
+  if (hipEventSynchronize(h->ev1) != hipSuccess) return -2;
+  float total = 0.f;
+  if (hipEventElapsedTime(&total, h->ev0, h->ev1) != hipSuccess) return -2;
+  *ms = total / (float)iters;
+  return 0;
+}
+
+int ffe_test_quat(int op, const float *a, const float *b, float *out, int n, void *stream) {
+  if (!a || !b || !out || n <= 0) return -1;
+  hipLaunchKernelGGL(test_quat_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), op, a, b, out, n);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

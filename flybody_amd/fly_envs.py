@@ -1,0 +1,64 @@
+"""Environment factories with the reference's names and keyword meaning (`vnl_ray/fly_envs.py`), returning
+batched MI355X environments instead of single-instance `composer.Environment`s.
+
+Built so far: `flight_imitation` (`fly_envs.py:29-72`).  `walk_on_ball`, `walk_imitation`, `vision_guided_flight`
+and `template_task` are the next rows of SURVEY.md section 8 and raise `NotImplementedError` for now.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .batched_env import BatchedFlyEnv
+from .tasks import synthetic, trajectories, wbpg
+
+
+def flight_imitation(wpg_pattern_path: str | None = None, ref_path: str | None = None, random_state=None,
+                     terminal_com_dist: float = 2.0, *, batch_size: int = 1, device: int = 0, env_id_base: int = 0,
+                     **env_kwargs) -> BatchedFlyEnv:
+    """Requires a fruitfly to track a flying reference (`fly_envs.py:29-72`).
+
+    Args:
+        wpg_pattern_path: `.npy` with one wing-beat cycle, shape (timesteps, 3) [yaw, roll, pitch], as the
+            reference's WingBeatPatternGenerator expects.  None = the build's synthetic cycle.
+        ref_path: `.npz` with `com_qpos (N,T,7)`, `com_qvel (N,T,6)`, `timestep_seconds` (the reference's HDF5 layout,
+            `tasks/trajectory_loaders.py:90-96`, converted; h5py is unavailable).  None = synthetic trajectories.
+        random_state: int seed or `np.random.RandomState`; seeds the per-env counter-based generators that draw the
+            trajectory index and the initial wing-beat phase of every episode.
+        terminal_com_dist: episode terminates when the model-to-ghost CoM distance exceeds this (cm).
+        batch_size, device, env_id_base: batching (env `i` of this handle is global env `env_id_base + i`).
+    """
+    if wpg_pattern_path is None:
+        tables = wbpg.build_tables(synthetic.base_wing_pattern())
+    else:
+        tables = wbpg.load_tables(wpg_pattern_path)
+    if ref_path is None:
+        com_qpos, com_qvel = synthetic.flight_trajectories()
+    else:
+        com_qpos, com_qvel, dt = trajectories.load_npz(ref_path)
+        if abs(dt - tables.dt_ctrl) > 1e-12:
+            raise ValueError(f"trajectory timestep {dt} != control timestep {tables.dt_ctrl}")
+    ref_qpos, ref_qvel = trajectories.preprocess(com_qpos, com_qvel)
+    if isinstance(random_state, np.random.RandomState):
+        seed = int(random_state.randint(0, 2**31 - 1))
+    else:
+        seed = 0 if random_state is None else int(random_state)
+    # fly_envs.py:54-65: time_limit 0.6 s, joint_filter 0 (compiled into the model), future_steps 5, initialize_qvel
+    return BatchedFlyEnv(tables, ref_qpos, ref_qvel, batch_size=batch_size, device=device, seed=seed, env_id_base=env_id_base,
+                         future_steps=5, time_limit=0.6, terminal_com_dist=terminal_com_dist, **env_kwargs)
+
+
+def walk_on_ball(*args, **kwargs):
+    raise NotImplementedError("walk_on_ball (contacts + ball arena) is the next SURVEY.md section 8 row; not built yet")
+
+
+def walk_imitation(*args, **kwargs):
+    raise NotImplementedError("walk_imitation is a 'next' row of SURVEY.md section 8(f); not built yet")
+
+
+def vision_guided_flight(*args, **kwargs):
+    raise NotImplementedError("vision-guided flight needs rendering + heightfield collision; out of scope (SURVEY.md 8f)")
+
+
+def template_task(*args, **kwargs):
+    raise NotImplementedError("template_task is a reference test scaffold; out of scope (SURVEY.md section 2 row 12)")

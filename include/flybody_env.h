@@ -1,0 +1,117 @@
+/*
+ * flybody_env.h - C ABI of the MI355X-native batched fruit-fly environment.
+ *
+ * The reference has no FFI on this path: its boundary is the Python dm_env.Environment protocol
+ * (SURVEY.md section 8b).  Each entry point below therefore names the reference *Python* interface
+ * it stands in for; the ctypes binding a maintainer adds on the reference side is shown in
+ * INTEGRATION.md, and flybody_amd/batched_env.py is that binding in this repo.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (ffe_last_error() has the text); nothing throws;
+ *   - all "dev" pointers are device (HBM) buffers owned by the caller; the library owns env state;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and never synchronise;
+ *   - one handle per (device, stream); handles are not thread-safe;
+ *   - layouts are row-major with the env index leading: act[B][A], obs[B][O].
+ */
+#ifndef FLYBODY_ENV_H_
+#define FLYBODY_ENV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ffe_env *ffe_handle;
+
+enum { FFE_STEP_FIRST = 0, FFE_STEP_MID = 1, FFE_STEP_LAST = 2 }; /* dm_env.StepType */
+
+/* physics switches (tests / BASELINE config 2 "constraints off"); 0 = everything on */
+enum {
+  FFE_NO_FLUID = 1, FFE_NO_LIMIT = 2, FFE_NO_DAMPER = 4, FFE_NO_SPRING = 8, FFE_NO_GRAVITY = 16, FFE_NO_ACTUATION = 32
+};
+
+/* Task inputs of fly_envs.flight_imitation (vnl_ray/fly_envs.py:29-72).  All host pointers, float64,
+ * copied during ffe_create. */
+typedef struct {
+  /* WingBeatPatternGenerator tables (vnl_ray/tasks/pattern_generators.py:18-119), built by the host */
+  int32_t wb_nfreq;            /* number of beat frequencies (201) */
+  const double *wb_beat_freqs; /* [nfreq] */
+  const int32_t *wb_tab_off;   /* [nfreq+1] row offsets */
+  const double *wb_traj;       /* [rows][6] wing angles */
+  const double *wb_phase;      /* [rows] */
+  double wb_base_freq, wb_rel_range, wb_rate, wb_dt_ctrl;
+  /* reference trajectories after the per-episode preprocessing of flight_imitation.py:97-104 */
+  int32_t ntraj, traj_len;
+  const double *ref_qpos; /* [ntraj][traj_len][7] ghost root pose */
+  const double *ref_qvel; /* [ntraj][traj_len][6] */
+  int32_t future_steps;     /* fly_envs.py:65 (5) */
+  int32_t time_limit_steps; /* round(time_limit / control_timestep), fly_envs.py:54 (3000) */
+  double terminal_com_dist; /* fly_envs.py:33 (2.0) */
+  double ghost_accel_z;     /* gravity felt by the armature-1 ghost, cm/s^2 */
+  int32_t pad_first_obs;    /* 0 = dm_control zero-padded sensor buffers at reset */
+  int32_t physics_flags;    /* FFE_NO_* */
+} ffe_flight_task;
+
+typedef struct {
+  int32_t batch, nq, nv, nu, action_dim, obs_dim, nsub;
+  double physics_timestep, control_timestep;
+  /* observation layout: offsets into the obs row, in the order dm_control emits the walker observables */
+  int32_t off_accelerometer, off_gyro, off_joints_pos, off_joints_vel, off_velocimeter, off_world_zaxis,
+      off_ref_displacement, off_ref_root_quat, n_obs_joints, n_ref;
+} ffe_spec_t;
+
+/* fly_envs.flight_imitation(...) -> composer.Environment (fly_envs.py:29-72); environment_factory() call
+ * site agents/ray_distributed_dmpo.py:314.  `model_blob` is the compiled model (flybody_amd/assets). */
+int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight_task *task, int batch, int device,
+                      uint64_t seed, uint64_t env_id_base, ffe_handle *out);
+int ffe_destroy(ffe_handle h);
+
+/* observation_spec()/action_spec()/reward_spec()/discount_spec() (ray_distributed_dmpo.py:315) */
+int ffe_spec(ffe_handle h, ffe_spec_t *spec);
+/* FruitFly.get_action_spec bounds (fruitfly/fruitfly.py:496-526); host arrays of action_dim floats */
+int ffe_action_bounds(ffe_handle h, float *minimum, float *maximum);
+
+/* Environment.reset() (acme loop, ray_distributed_dmpo.py:404): every env starts a new episode and reports
+ * FIRST.  Outputs as in ffe_step. */
+int ffe_reset(ffe_handle h, float *obs_dev, float *reward_dev, float *discount_dev, int32_t *step_type_dev,
+              void *stream);
+/* Environment.step(action) (ray_distributed_dmpo.py:404 via acme.EnvironmentLoop.run_episode): one control step of
+ * every env = before_step, nsub physics substeps, reward, discount, termination, observation
+ * (tasks/flight_imitation.py:149-220, tasks/base.py:190-217).  An env that returned LAST performs its reset on
+ * this call instead and returns FIRST (reward 0, discount 1), exactly as dm_control auto-resets.
+ * act_dev[B][action_dim] is in the raw action spec and is not modified. */
+int ffe_step(ffe_handle h, const float *act_dev, float *obs_dev, float *reward_dev, float *discount_dev,
+             int32_t *step_type_dev, void *stream);
+
+/* FlightImitationWBPG.set_next_trajectory_index (flight_imitation.py:87-91), plus the initial wing-beat phase
+ * the reference draws from its RandomState (flight_imitation.py:137).  Host arrays [B]; traj_idx<0 keeps the
+ * counter-based draw.  Applies to each env's next reset only. */
+int ffe_force_next_episode(ffe_handle h, const int32_t *traj_idx_host, const double *phase_host);
+
+/* physics.get_state()/set_state() analogue for parity tests: qpos[B][nq] (root position first), qvel[B][nv],
+ * float64 device buffers.  set_state leaves task counters untouched. */
+int ffe_get_state(ffe_handle h, double *qpos_dev, double *qvel_dev, void *stream);
+int ffe_set_state(ffe_handle h, const double *qpos_dev, const double *qvel_dev, void *stream);
+/* task-side state per env: {wbpg_step, wbpg_freq_idx, step_counter, traj_idx, needs_reset, n_active_limits,
+ * solver_iters, reserved} int32[B][8] and {wbpg_ctrl_freq, ghost_pos[3], ghost_quat[4]} float64[B][8] */
+int ffe_get_task_state(ffe_handle h, int32_t *ints_dev, double *reals_dev, void *stream);
+
+/* name and duration helper for bench.py's roofline: launches `iters` steps bracketed by HIP events on `stream`
+ * and returns the mean milliseconds per ffe_step launch (synchronises the stream). */
+int ffe_time_steps(ffe_handle h, const float *act_dev, float *obs_dev, float *reward_dev, float *discount_dev,
+                   int32_t *step_type_dev, int iters, void *stream, float *ms_per_step);
+
+/* device unit test of the in-kernel quaternion helpers against vnl_ray/quaternions.py goldens:
+ * op 0 mult_quat(a,b) 1 reciprocal_quat(a) 2 rotate_vec_with_quat(a.xyz,b) 3 quat_dist_short_arc(a,b)
+ * 4 get_dquat_local(a,b); a,b,out are device float[n][4] */
+int ffe_test_quat(int op, const float *a_dev, const float *b_dev, float *out_dev, int n, void *stream);
+
+const char *ffe_last_error(ffe_handle h);
+const char *ffe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLYBODY_ENV_H_ */

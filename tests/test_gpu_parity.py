@@ -1,0 +1,221 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (flybody_amd.BatchedFlyEnv -> ctypes ->
+libflybody_env.so), against the float64 CPU oracle on identical inputs.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import BLOB
+
+pytestmark = pytest.mark.gpu
+
+# float32 tolerances (stated per BASELINE.json north_star); measured headroom is recorded in DESIGN.md
+TOL_OBS_1STEP = 2e-4      # teacher-forced, one control step, scaled by max(1, |x|)
+TOL_REWARD_1STEP = 1e-5
+TOL_REWARD_OPEN_100 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def setup(torch_mod, wb_tables, ref_traj):
+    from flybody_amd.batched_env import BatchedFlyEnv
+    from oracle import oracle as O
+
+    B = 16
+    env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=3)
+    om = O.OracleModel(BLOB)
+    oenvs = [O.OracleFlightEnv(om, wb_tables, *ref_traj, ghost_accel_z=env.ghost_accel_z, seed=3, env_id=i) for i in range(B)]
+    return env, oenvs
+
+
+def _scaled_err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def test_device_quaternion_helpers(torch_mod, golden_quat):
+    import ctypes as C
+
+    from flybody_amd import _capi
+
+    torch, g, L = torch_mod, golden_quat, _capi.lib()
+    dev = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float32, device="cuda")
+    n = len(g["q1"])
+    out = torch.zeros(n, 4, dtype=torch.float32, device="cuda")
+
+    def run(op, a, b):
+        assert L.ffe_test_quat(op, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, None) == 0
+        torch.cuda.synchronize()
+        return out.cpu().numpy().astype(np.float64)
+
+    q1, q2, u1, u2 = dev(g["q1"]), dev(g["q2"]), dev(g["u1"]), dev(g["u2"])
+    v4 = dev(np.concatenate((g["v"], np.zeros((n, 1))), 1))
+    assert _scaled_err(run(0, q1, q2), g["mult_quat"]) < 2e-6
+    assert _scaled_err(run(1, q1, q1), g["reciprocal_quat"]) < 2e-6
+    assert _scaled_err(run(2, v4, u1)[:, :3], g["rotate_vec_with_quat"]) < 3e-6
+    assert np.max(np.abs(run(3, u1, u2)[:, 0] - g["quat_dist_short_arc"])) < 2e-3  # acos near 0/pi amplifies float32 rounding
+    assert _scaled_err(run(4, u1, u2), g["get_dquat_local"]) < 2e-6
+    assert np.isfinite(run(3, u1, u1)).all()
+
+
+def _oracle_reset(oenvs, traj, phase):
+    out = []
+    for i, e in enumerate(oenvs):
+        e.force_next(int(traj[i]), float(phase[i]))
+        out.append(e.step(np.zeros(e.naction)))
+    return out
+
+
+def test_reset_matches_oracle(setup, torch_mod):
+    env, oenvs = setup
+    B = env.batch_size
+    rng = np.random.RandomState(0)
+    traj, phase = rng.randint(0, 8, B), rng.uniform(0, 0.95, B)
+    env.set_next_trajectory_index(traj, phase)
+    ts = env.reset()
+    torch_mod.cuda.synchronize()
+    ref = _oracle_reset(oenvs, traj, phase)
+    obs = env.flat_observation.cpu().numpy().astype(np.float64)
+    assert (ts.step_type.cpu().numpy() == 0).all()
+    qpos, qvel = [x.cpu().numpy() for x in env.get_state()]
+    ints, reals = [x.cpu().numpy() for x in env.get_task_state()]
+    for i in range(B):
+        st, r, d, o = ref[i]
+        assert st == 0
+        assert _scaled_err(qpos[i], oenvs[i].data.qpos) < 1e-6 and _scaled_err(qvel[i], oenvs[i].data.qvel) < 1e-5
+        wstep, widx, wcf = oenvs[i].wbpg_state()
+        assert ints[i, 0] == wstep and ints[i, 1] == widx and reals[i, 0] == wcf
+        assert _scaled_err(obs[i], o) < TOL_OBS_1STEP, (i, np.argmax(np.abs(obs[i] - o)))
+
+
+def test_counter_rng_matches_oracle(setup, torch_mod):
+    """Without forcing, trajectory index and wing phase come from the shared counter-based generator."""
+    from oracle import oracle as O
+
+    env, oenvs = setup
+    env.reset()
+    torch_mod.cuda.synchronize()
+    ints, _ = [x.cpu().numpy() for x in env.get_task_state()]
+    # second episode of this handle (fixture reset once already): episode counters advance per env
+    for i in range(env.batch_size):
+        found = any(ints[i, 3] == O.rng_u64(3, i, ep, 0) % 8 for ep in range(0, 6))
+        assert found
+
+
+def _rollout(env, oenvs, torch, steps, teacher, seed, act_scale=1.0):
+    B = env.batch_size
+    rng = np.random.RandomState(seed)
+    amin, amax = env.action_spec().minimum, env.action_spec().maximum
+    traj, phase = rng.randint(0, 8, B), rng.uniform(0, 0.95, B)
+    env.set_next_trajectory_index(traj, phase)
+    env.reset()
+    _oracle_reset(oenvs, traj, phase)
+    errs = dict(obs=[], reward=[], qpos=[], qvel=[])
+    alive = np.ones(B, bool)
+    for k in range(steps):
+        a = (amin + (amax - amin) * (0.5 + 0.5 * act_scale * rng.uniform(-1, 1, (B, len(amin))))).astype(np.float32)
+        ts = env.step(torch.tensor(a, device="cuda"))
+        obs = env.flat_observation.cpu().numpy().astype(np.float64)
+        rew, disc, st = ts.reward.cpu().numpy(), ts.discount.cpu().numpy(), ts.step_type.cpu().numpy()
+        qpos, qvel = [x.cpu().numpy() for x in env.get_state()]
+        ints, reals = [x.cpu().numpy() for x in env.get_task_state()]
+        eo, er, eq, ev = 0.0, 0.0, 0.0, 0.0
+        for i in range(B):
+            if not alive[i]:
+                continue
+            ost, orr, od, oo = oenvs[i].step(a[i].astype(np.float64))
+            ws, wi, wc = oenvs[i].wbpg_state()
+            assert (ints[i, 0], ints[i, 1]) == (ws, wi) and reals[i, 0] == wc, ("wbpg", k, i)
+            if ost != st[i]:
+                # termination decided on a threshold crossing may flip under float32; stop comparing this env
+                alive[i] = False
+                continue
+            assert od == disc[i]
+            eo = max(eo, _scaled_err(obs[i], oo)); er = max(er, abs(rew[i] - orr))
+            eq = max(eq, _scaled_err(qpos[i], oenvs[i].data.qpos)); ev = max(ev, _scaled_err(qvel[i], oenvs[i].data.qvel))
+            if ost == 2:
+                alive[i] = False
+        errs["obs"].append(eo); errs["reward"].append(er); errs["qpos"].append(eq); errs["qvel"].append(ev)
+        if teacher:
+            q = np.stack([e.data.qpos for e in oenvs]); v = np.stack([e.data.qvel for e in oenvs])
+            env.set_state(torch.tensor(q), torch.tensor(v))
+        if not alive.any():
+            break
+    return {k: np.array(v) for k, v in errs.items()}, alive
+
+
+def test_teacher_forced_step_parity(setup, torch_mod):
+    """Every control step starts from the oracle's state: per-step error of the HIP path, 200 steps x 16 envs."""
+    env, oenvs = setup
+    errs, alive = _rollout(env, oenvs, torch_mod, 200, teacher=True, seed=11, act_scale=0.3)
+    print("teacher-forced max errs", {k: float(v.max()) for k, v in errs.items()})
+    assert errs["obs"].max() < TOL_OBS_1STEP
+    assert errs["reward"].max() < TOL_REWARD_1STEP
+
+
+def test_open_loop_drift(setup, torch_mod):
+    """No state resynchronisation: float32 drift of reward over 100 control steps (400 physics substeps)."""
+    env, oenvs = setup
+    errs, alive = _rollout(env, oenvs, torch_mod, 100, teacher=False, seed=12, act_scale=0.3)
+    print("open-loop reward err @10,50,100:", errs["reward"][[9, 49, min(99, len(errs["reward"]) - 1)]], "qpos", errs["qpos"][-1])
+    assert errs["reward"].max() < TOL_REWARD_OPEN_100
+
+
+def test_auto_reset_semantics(torch_mod, wb_tables, ref_traj):
+    """LAST is followed by FIRST on the next step call, per env (dm_control composer semantics)."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+
+    torch = torch_mod
+    env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=64, seed=1, terminal_com_dist=0.05)
+    ts = env.reset()
+    assert (ts.step_type.cpu().numpy() == 0).all()
+    a = torch.zeros(64, 12, device="cuda")
+    prev = ts.step_type.cpu().numpy().copy()
+    saw_last = False
+    for _ in range(60):
+        ts = env.step(a)
+        st = ts.step_type.cpu().numpy()
+        assert (st[prev == 2] == 0).all()           # LAST -> FIRST
+        assert (st[prev != 2] != 0).all()           # no spurious FIRST
+        d = ts.discount.cpu().numpy()
+        assert (d[st == 0] == 1).all() and (ts.reward.cpu().numpy()[st == 0] == 0).all()
+        saw_last |= (st == 2).any()
+        prev = st.copy()
+    assert saw_last  # zero action: the fly falls away from the ghost and exceeds the 0.05 cm bound
+    env.close()
+
+
+def test_full_batch_properties(torch_mod, wb_tables, ref_traj):
+    """BASELINE config 4 size (B=8192): finiteness, determinism and batch-independence of the results."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+
+    torch = torch_mod
+    B = 8192
+    outs = []
+    for rep in range(2):
+        env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=5)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for _ in range(20):
+            a = (torch.rand(B, 12, device="cuda", generator=g) * 2 - 1) * 0.3
+            ts = env.step(a)
+        torch.cuda.synchronize()
+        outs.append((env.flat_observation.clone(), ts.reward.clone(), ts.step_type.clone()))
+        env.close()
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # bitwise reproducible
+    assert ((outs[0][1] >= 0) & (outs[0][1] <= 1)).all()
+    # the same env run inside a small batch gives the same bits (no cross-env coupling)
+    env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=64, seed=5)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(20):
+        a = (torch.rand(B, 12, device="cuda", generator=g) * 2 - 1) * 0.3
+        ts = env.step(a[:64].contiguous())
+    assert torch.equal(env.flat_observation, outs[0][0][:64])
+    env.close()
