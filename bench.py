@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/s of the batched flight-imitation environment on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one control step (4 physics substeps + WBPG + observation/reward/termination/auto-reset) of every
+env = one launch of `flight_step_kernel`.  Workload = BASELINE.json configs[3]: flight-imitation, B = 8192 envs
+per GPU (config 5 = the same on 8 GPUs), synthetic wing-beat pattern and reference trajectories, canonical
+U(-1,1) actions already resident in HBM.  For N>1 each rank owns 8192 envs (weak scaling, no data-path
+collective inside the physics) and every step ends with the RCCL gather of (obs, reward, discount, step_type)
+to rank 0 that a central learner needs.
+
+One JSON line on rank 0; `roofline` is measured live with HIP events on the launch stream; `cpu_baseline` times
+the float64 CPU oracle (oracle/, the checker - never the product) on the host cores, at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 8192
+ALGO_BYTES_PER_ENV_STEP = 1408  # reads 624 + writes 784 (fp32 state, minimal I/O)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def _cpu_worker(args):
+    """One oracle env per process, `steps` control steps of the same workload; returns (steps, seconds)."""
+    idx, steps = args
+    import numpy as np
+
+    from flybody_amd.tasks.synthetic import base_wing_pattern, flight_trajectories
+    from flybody_amd.tasks.trajectories import preprocess
+    from flybody_amd.tasks.wbpg import build_tables
+    from oracle import oracle as O
+
+    tables = build_tables(base_wing_pattern())
+    rq, rv = preprocess(*flight_trajectories(8, 3006))
+    m = O.OracleModel(os.path.join(ROOT, "flybody_amd", "assets", "fly_flight.ffmb"))
+    env = O.OracleFlightEnv(m, tables, rq, rv, seed=0, env_id=idx)
+    rng = np.random.RandomState(idx)
+    amin = np.array([-0.2, -3, -0.5, -1, -1, -1, -1, -1, -1, -0.7, -1.05, -1.0])
+    amax = np.array([0.2, 3, 0.3, 1, 1, 1, 1, 1, 1, 0.7, 0.7, 1.0])
+    acts = amin + (amax - amin) * (0.5 + 0.5 * rng.uniform(-1, 1, (steps, 12)))
+    for k in range(50):
+        env.step(acts[k])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(acts[k])
+    return steps, time.perf_counter() - t0
+
+
+def cpu_baseline(target_seconds=15.0):
+    """Oracle ("port") on all host cores, one env per process as the reference runs its actors
+    (train_dmpo_ray.py:432-452).  Must run before this process touches the GPU (fork)."""
+    import multiprocessing as mp
+
+    from oracle import oracle as O
+
+    O.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    steps, dt = _cpu_worker((0, 1500))
+    per_core = steps / dt
+    n = int(max(500, per_core * target_seconds))
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(i, n) for i in range(cores)])
+    wall = max(r[1] for r in res)
+    value = sum(r[0] for r in res) / wall
+    return {"value": round(value, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x 1 float64 oracle env x {n} control steps of the same flight-imitation workload "
+                      f"(single-core {per_core:.0f} env-steps/s; pool wall {time.perf_counter() - t0:.1f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()  # before any GPU initialisation (uses fork)
+
+    import torch
+    import torch.distributed as dist
+
+    from flybody_amd import fly_envs
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.envs_per_gpu
+    env = fly_envs.flight_imitation(batch_size=B, device=local_rank, random_state=0, env_id_base=rank * B)
+    spec = env.action_spec()
+    lo = torch.tensor(spec.minimum, device=dev)
+    hi = torch.tensor(spec.maximum, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    npool = 16
+    acts = [(lo + (hi - lo) * torch.rand(B, spec.shape[0], device=dev, generator=g)).contiguous() for _ in range(npool)]
+
+    # the per-step gather of everything a central learner consumes
+    pack = torch.empty(B, env.spec.obs_dim + 3, dtype=torch.float32, device=dev)
+    gather_list = [torch.empty_like(pack) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def one_step(k):
+        ts = env.step(acts[k % npool])
+        if world > 1:
+            pack[:, : env.spec.obs_dim] = env.flat_observation
+            pack[:, -3] = ts.reward
+            pack[:, -2] = ts.discount
+            pack[:, -1] = ts.step_type.to(torch.float32)
+            dist.gather(pack, gather_list, dst=0)
+        return ts
+
+    env.reset()
+    for k in range(args.warmup):
+        one_step(k)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: mean launch duration by HIP events on the launch stream, same workload
+    k_ms = env.time_steps(acts[0], min(args.steps, 100))
+    torch.cuda.synchronize(dev)
+
+    if rank == 0:
+        total_env_steps = world * B * args.steps
+        value = total_env_steps / elapsed
+        achieved = ALGO_BYTES_PER_ENV_STEP * B / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), fruitfly flight-imitation task",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "flight_imitation (BASELINE configs[3]): 4 substeps @5e-5 s + WBPG + obs/reward/termination/auto-reset",
+                       "envs_per_gpu": B, "global_batch": world * B, "parallelism": f"env-sharded x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                       "actions": "uniform over the raw action spec (canonical U(-1,1)), resident in HBM"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "kernel": "flight_step_kernel", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
+                         "note": "fused wave-per-env step keeps state on chip; VALU/LDS-latency bound, not HBM bound (DESIGN.md)"},
+            "physics_substeps_per_s": round(value * env.spec.nsub, 1),
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
