@@ -54,7 +54,7 @@ def _cpu_worker(args):
     return steps, time.perf_counter() - t0
 
 
-def cpu_baseline(target_seconds=15.0):
+def cpu_baseline(target_seconds=8.0):
     """Oracle ("port") on all host cores, one env per process as the reference runs its actors
     (train_dmpo_ray.py:432-452).  Must run before this process touches the GPU (fork)."""
     import multiprocessing as mp
@@ -63,10 +63,11 @@ def cpu_baseline(target_seconds=15.0):
 
     O.build()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
+    # a one-GPU box shares its host: stay within the 16-core share unless told otherwise
+    cores = max(1, min(cores, int(os.environ.get("FLYBODY_BENCH_CORES", "16"))))
     steps, dt = _cpu_worker((0, 1500))
     per_core = steps / dt
-    n = int(max(500, per_core * target_seconds))
+    n = int(max(500, 0.7 * per_core * target_seconds))
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:

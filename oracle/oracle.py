@@ -72,6 +72,7 @@ def lib():
         L.fo_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_env_force_next.argtypes = [vp, C.c_int, C.c_double]
         L.fo_env_set_pad_first_obs.argtypes = [vp, C.c_int]
+        L.fo_env_request_reset.argtypes = [vp]
         L.fo_env_data.restype = vp
         L.fo_env_data.argtypes = [vp]
         L.fo_env_ghost.argtypes = [vp, dp]
@@ -210,6 +211,11 @@ class OracleFlightEnv:
 
     def set_pad_first_obs(self, v: bool):
         self.L.fo_env_set_pad_first_obs(self.ptr, int(v))
+
+    def reset(self):
+        """dm_env reset(): returns the FIRST timestep of a new episode."""
+        self.L.fo_env_request_reset(self.ptr)
+        return self.step(np.zeros(self.naction))
 
     def step(self, action):
         a = np.ascontiguousarray(action, dtype=np.float64)

@@ -78,7 +78,7 @@ def _oracle_reset(oenvs, traj, phase):
     out = []
     for i, e in enumerate(oenvs):
         e.force_next(int(traj[i]), float(phase[i]))
-        out.append(e.step(np.zeros(e.naction)))
+        out.append(e.reset())
     return out
 
 
