@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libflybody_env.so")
+LIB_PATH = os.environ.get("FLYBODY_ENV_LIB") or os.path.join(_HERE, "csrc", "libflybody_env.so")  # override: tuning variants only
 
 SYMBOLS = [
     "ffe_create_flight", "ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step",

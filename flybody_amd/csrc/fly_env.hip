@@ -23,6 +23,10 @@
 #include "../../include/flybody_env.h"
 #include "dev_model.hpp"
 
+#ifndef FFE_WAVES_PER_SIMD
+#define FFE_WAVES_PER_SIMD 2  // register budget = 512 / this; picked by measurement
+#endif
+
 namespace ffe {
 
 // ------------------------------------------------------------------------------------------------ state
@@ -50,22 +54,29 @@ struct TaskDev {
 struct alignas(16) Tile {
   float qpos[kMaxDof + 4];
   float qvel[kMaxDof + 4];
-  float lT[kMaxLink][8];      // link frame in its parent link: pos[3], quat[4]
-  float xpos[kMaxLink][4];    // world (root-relative) link origin
-  float xmat[kMaxLink][12];   // world link orientation (9 used)
-  float cinert[kMaxLink][12]; // 10 used
-  float crb[kMaxLink][12];
-  float cdof[kMaxDof][8];     // 6 used
-  float cdofd[kMaxDof][8];
-  float buf[kMaxDof][8];
-  float la[kMaxLink][8];      // per-link scratch (6 used)
-  float lb[kMaxLink][8];
-  float lc[kMaxLink][8];
+  float xpos[kMaxLink][3];    // world (root-relative) link origin
+  float xmat[kMaxLink][9];    // world link orientation
+  float cinert[kMaxLink][10]; // link spatial inertia about the com reference point
+  float crb[kMaxLink][10];    // composite (subtree) inertia
+  float cdof[kMaxDof][6];     // dof axes, com-centred world frame
+  union {
+    float cdofd[kMaxDof][6];  // cdof_dot; dead once the per-link sums A1 are taken
+    float buf[kMaxDof][6];    // crb * cdof
+  };
+  union {
+    float lT[kMaxLink][7];    // link frame in its parent link: pos[3], quat[4]; dead after K2
+    float la[kMaxLink][6];    // per-link scratch
+  };
+  float lb[kMaxLink][6];
+  float lc[kMaxLink][6];
   float M[kMaxM];
   float LD[kMaxM];
   float dinv[kLanePad];
   float x[kLanePad];
   float frc[kMaxAct];
+  float sens[12];    // running sums of the buffered sensors: acc[3], gyro[3], vel[3]
+  double rootpos[4];  // free-joint position in float64
+  double ghost[16];   // pos[3], quat[4], vel[3], angvel[3]
 };
 
 // ------------------------------------------------------------------------------------------------ maths
@@ -247,7 +258,7 @@ __device__ __forceinline__ unsigned long long env_rng(unsigned long long seed, u
 
 // ------------------------------------------------------------------------------------------------ per-wave context
 struct Ctx {
-  const DevModel &M;
+  const DevModel *Mp;
   Tile &T;
   int lane;
   int flags;
@@ -267,7 +278,7 @@ struct Ctx {
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
 __device__ void stage1(Ctx &c) {
-  const DevModel &M = c.M;
+  const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_link = lane < M.nlink, is_dof = lane < M.nv;
@@ -466,7 +477,7 @@ __device__ void stage1(Ctx &c) {
 
 // mj: mj_factorI on (M + diag(add)); rows are left unscaled and 1/D kept aside (T.dinv).
 __device__ void factor(Ctx &c, float add) {
-  const DevModel &M = c.M;
+  const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
   for (int e = lane; e < M.nM; e += kWave) T.LD[e] = T.M[e];
@@ -491,7 +502,7 @@ __device__ void factor(Ctx &c, float add) {
 
 // mj: mj_solveLD with the factor above.  `rhs` per dof lane in, solution per dof lane out.
 __device__ float solve(Ctx &c, float rhs) {
-  const DevModel &M = c.M;
+  const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_dof = lane < M.nv;
@@ -530,8 +541,8 @@ struct StepOut {
 
 // Stage 2 = mj_fwdActuation, mj_fwdAcceleration, mj_fwdConstraint (joint limits), accelerometer, mj_Euler.
 // `ctrl_force` is the per-dof generalized actuator force, already assembled.
-__device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, double *rootpos, unsigned long long &lo_mask, unsigned long long &hi_mask, int &iters_out) {
-  const DevModel &M = c.M;
+__device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long &lo_mask, unsigned long long &hi_mask, int &iters_out) {
+  const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_dof = lane < M.nv;
@@ -620,9 +631,9 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, double *rootpos, un
   SYNC();
   if (lane == 0) {
     // free joint: position in float64, orientation by mju_quatIntegrate with the body-frame angular velocity
-    rootpos[0] += (double)h * (double)T.qvel[0];
-    rootpos[1] += (double)h * (double)T.qvel[1];
-    rootpos[2] += (double)h * (double)T.qvel[2];
+    T.rootpos[0] += (double)h * (double)T.qvel[0];
+    T.rootpos[1] += (double)h * (double)T.qvel[1];
+    T.rootpos[2] += (double)h * (double)T.qvel[2];
     V3 w = {T.qvel[3], T.qvel[4], T.qvel[5]};
     float n = sqrtf(dot(w, w));
     Q4 q = qnormalize(Q4{T.qpos[3], T.qpos[4], T.qpos[5], T.qpos[6]});
@@ -638,7 +649,7 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, double *rootpos, un
 
 // mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.
 __device__ float actuation(Ctx &c, const float *ctrl_lds) {
-  const DevModel &M = c.M;
+  const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
   if (c.flags & FFE_NO_ACTUATION) return 0.f;
@@ -664,6 +675,15 @@ __device__ float actuation(Ctx &c, const float *ctrl_lds) {
 }
 
 // ------------------------------------------------------------------------------------------------ task helpers
+// The wing-beat frequency filter feeds an argmin over a frequency grid, so one ulp decides which table is
+// used: evaluate it exactly as numpy does (separate multiplies and adds, no FMA contraction).
+__device__ __noinline__ double wbpg_filter(double cf, double rate, double base, double rel, double act) {
+#pragma clang fp contract(off)
+  double cmd = base * (1.0 + rel * act);
+  double a = cf * rate;
+  double b = cmd * (1.0 - rate);
+  return a + b;
+}
 // argmin_i |table[i] - x| with numpy's first-minimum tie-break, across the wave (float64, bit-compatible
 // with the reference's np.argmin(np.abs(...)) on the same tables; ref: pattern_generators.py:148,179,186)
 __device__ int wave_argmin_absdiff(const double *tab, int n, double x, int lane) {
@@ -691,9 +711,9 @@ __device__ __forceinline__ ObsLayout obs_layout(int nj, int nref) {
 
 // Observation assembly (ref: fruitfly.py:532-708 enabled set per tasks/base.py:167-168 + flight_imitation.py:84-85;
 // ref_displacement / ref_root_quat: tasks/base.py:237-261).  Returns |ref_displacement[0]| and ref_root_quat[0].
-__device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, const double *rootpos, int traj_idx, int step_counter,
+__device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_idx, int step_counter,
                           float &com_dist, Q4 &rq0) {
-  const DevModel &M = c.M;
+  const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
   const int nref = K.future_steps + 1;
@@ -712,7 +732,7 @@ __device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_g
   Q4 r0 = {1.f, 0.f, 0.f, 0.f};
   if (lane < nref) {
     const double *r = K.ref_qpos + ((size_t)traj_idx * K.traj_len + step_counter + lane) * 7;
-    V3 dv = {(float)(r[0] - rootpos[0]), (float)(r[1] - rootpos[1]), (float)(r[2] - rootpos[2])};
+    V3 dv = {(float)(r[0] - T.rootpos[0]), (float)(r[1] - T.rootpos[1]), (float)(r[2] - T.rootpos[2])};
     V3 e = mtv(ldm(T.xmat[0]), dv);
     obs[L.rdisp + 3 * lane] = e.x; obs[L.rdisp + 3 * lane + 1] = e.y; obs[L.rdisp + 3 * lane + 2] = e.z;
     Q4 fq = {T.qpos[3], T.qpos[4], T.qpos[5], T.qpos[6]};
@@ -725,7 +745,7 @@ __device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_g
 }
 
 __device__ __forceinline__ void load_lane_consts(Ctx &c) {
-  const DevModel &M = c.M;
+  const DevModel &M = *c.Mp;
   const int lane = c.lane;
   c.d_link = M.d_link[lane]; c.d_kind = M.d_kind[lane]; c.d_madr = M.d_madr[lane]; c.d_depth = M.d_depth[lane]; c.d_parent = M.d_parent[lane];
   c.l_par = M.l_parent[lane]; c.l_dofadr = M.l_dofadr[lane]; c.l_dofnum = M.l_dofnum[lane]; c.l_sub = M.l_sub[lane];
@@ -739,7 +759,7 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
 
 // ------------------------------------------------------------------------------------------------ the step kernel
 // One launch = one dm_env step of every env.  mode: 0 = step (auto-reset envs that ended), 1 = reset all.
-__global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *__restrict__ Mp, const TaskDev *__restrict__ Kp, EnvState *__restrict__ states, const float *__restrict__ act,
+__global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(const DevModel *__restrict__ Mp, const TaskDev *__restrict__ Kp, EnvState *__restrict__ states, const float *__restrict__ act,
                                                               float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                               float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode) {
   __shared__ Tile T;
@@ -749,12 +769,13 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
   if (env >= batch) return;
   const int lane = threadIdx.x;
   EnvState &S = states[env];
-  Ctx c{M, T, lane, K.flags};
+  Ctx c{Mp, T, lane, K.flags};
   load_lane_consts(c);
   float *obs = obs_out + (size_t)env * K.obs_dim;
   const int nsub = M.nsub;
 
-  double rootpos[3] = {S.rootpos[0], S.rootpos[1], S.rootpos[2]};
+  if (lane < 3) T.rootpos[lane] = S.rootpos[lane];
+  if (lane < 9) T.sens[lane] = 0.f;
   unsigned long long lo_mask = S.lo_mask, hi_mask = S.hi_mask;
   int wb_step = S.wb_step, wb_idx = S.wb_freq_idx, step_counter = S.step_counter, traj_idx = S.traj_idx;
   double wb_cf = S.wb_ctrl_freq;
@@ -764,7 +785,6 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
   // ---- prepare: either start a new episode or load the env's state and run the task pre-step
   unsigned long long episode = S.episode;
   float ctrl_reg = 0.f;
-  double gpos[3] = {0, 0, 0}, gvel[3] = {0, 0, 0}, gq[4] = {1, 0, 0, 0}, gw[3] = {0, 0, 0};
   if (do_reset) {
     // ref: flight_imitation.py:93-147 + composer reset
     double phase;
@@ -788,9 +808,8 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
       T.qpos[3] = (float)rq[3]; T.qpos[4] = (float)rq[4]; T.qpos[5] = (float)rq[5]; T.qpos[6] = (float)rq[6];
       T.qvel[0] = (float)rv[0]; T.qvel[1] = (float)rv[1]; T.qvel[2] = (float)rv[2];  // initialize_qvel: linear only
     }
-    rootpos[0] = rq[0]; rootpos[1] = rq[1]; rootpos[2] = rq[2];
-    for (int k = 0; k < 3; k++) gpos[k] = rq[k];
-    for (int k = 0; k < 4; k++) gq[k] = rq[3 + k];
+    if (lane < 7) T.ghost[lane] = rq[lane];
+    if (lane < 3) T.rootpos[lane] = rq[lane];
     if (lane < M.nwing) {
       float q0 = K.traj[(size_t)(off + wb_step) * 6 + lane], q1 = K.traj[(size_t)(off + nxt) * 6 + lane];
       T.qpos[M.wing_qadr[lane]] = q0;
@@ -805,12 +824,11 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
     const float *a_in = act + (size_t)env * M.naction;
     float act_user = a_in[M.user_action];
     if (!(act_user == act_user)) act_user = 0.f;
-    double cmd = K.base_freq * (1.0 + K.rel_range * (double)act_user);
     {
       // ref: pattern_generators.py:159-191 step
       int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
       wb_step = (wb_step + 1) % len;
-      wb_cf = wb_cf * K.rate + cmd * (1.0 - K.rate);
+      wb_cf = wbpg_filter(wb_cf, K.rate, K.base_freq, K.rel_range, (double)act_user);
       int idx_new = wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane);
       if (idx_new != wb_idx) {
         double cur = K.phase_frac[off + wb_step];
@@ -836,21 +854,26 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
     ctrl_reg = lane < M.nu ? T.x[lane] : 0.f;
     SYNC();
     const double *rq = K.ref_qpos + ((size_t)traj_idx * K.traj_len + step_counter) * 7, *rv = K.ref_qvel + ((size_t)traj_idx * K.traj_len + step_counter) * 6;
-    for (int k = 0; k < 3; k++) { gpos[k] = rq[k]; gvel[k] = rv[k]; gw[k] = rv[3 + k]; }
-    for (int k = 0; k < 4; k++) gq[k] = rq[3 + k];
+    if (lane < 7) T.ghost[lane] = rq[lane];
+    else if (lane < 13) T.ghost[lane] = rv[lane - 7];
     step_counter++;
   }
   // ---- physics.  dm_control's legacy step is mj_step2 then mj_step1, so the position/velocity stage is evaluated
   //      once up front and again after every integration; buffered sensors take one sample per substep.  A reset
   //      is the same pipeline run once without actuation and without integrating (mj_forward).
-  V3 s_acc = {0.f, 0.f, 0.f}, s_gyro = {0.f, 0.f, 0.f}, s_vel = {0.f, 0.f, 0.f};
   const int nst = do_reset ? 1 : nsub;
 #pragma unroll 1
   for (int s = 0; s <= nst; s++) {
+    {
+      const DevModel *ml = Mp;
+      asm volatile("" : "+s"(ml));
+      c.Mp = ml;
+    }
     stage1(c);
-    if (do_reset || s > 0) {
-      s_gyro = s_gyro + V3{T.qvel[3], T.qvel[4], T.qvel[5]};
-      s_vel = s_vel + mtv(ldm(T.xmat[0]), V3{T.qvel[0], T.qvel[1], T.qvel[2]});
+    if (lane == 0 && (do_reset || s > 0)) {
+      V3 v = mtv(ldm(T.xmat[0]), V3{T.qvel[0], T.qvel[1], T.qvel[2]});
+      T.sens[3] += T.qvel[3]; T.sens[4] += T.qvel[4]; T.sens[5] += T.qvel[5];
+      T.sens[6] += v.x; T.sens[7] += v.y; T.sens[8] += v.z;
     }
     if (s == nst) break;
     float qa = 0.f;
@@ -860,36 +883,45 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
       qa = actuation(c, T.frc);
     }
     int it = 0;
-    s_acc = s_acc + stage2(c, qa, !do_reset, rootpos, lo_mask, hi_mask, it);
+    V3 acc = stage2(c, qa, !do_reset, lo_mask, hi_mask, it);
     iters += it;
-    if (do_reset) break;
-    rootpos[0] = __shfl(rootpos[0], 0); rootpos[1] = __shfl(rootpos[1], 0); rootpos[2] = __shfl(rootpos[2], 0);
-    // ghost: armature-1 free body coasting at the reference velocity (closed form, float64)
-    gvel[2] += (double)M.h * K.ghost_accel_z;
-    for (int k = 0; k < 3; k++) gpos[k] += (double)M.h * gvel[k];
-    double n = sqrt(gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2]);
-    double qn = sqrt(gq[0] * gq[0] + gq[1] * gq[1] + gq[2] * gq[2] + gq[3] * gq[3]);
-    for (int k = 0; k < 4; k++) gq[k] /= qn;
-    if (n >= 1e-15) {
-      double sh, ch;
-      sincos(0.5 * n * (double)M.h, &sh, &ch);
-      double ax = gw[0] / n * sh, ay = gw[1] / n * sh, az = gw[2] / n * sh;
-      double w = gq[0] * ch - gq[1] * ax - gq[2] * ay - gq[3] * az, x = gq[0] * ax + gq[1] * ch + gq[2] * az - gq[3] * ay,
-             y = gq[0] * ay - gq[1] * az + gq[2] * ch + gq[3] * ax, z = gq[0] * az + gq[1] * ay - gq[2] * ax + gq[3] * ch;
-      double m = sqrt(w * w + x * x + y * y + z * z);
-      gq[0] = w / m; gq[1] = x / m; gq[2] = y / m; gq[3] = z / m;
+    if (lane == 0) {
+      T.sens[0] += acc.x; T.sens[1] += acc.y; T.sens[2] += acc.z;
+      if (!do_reset) {
+        // ghost: armature-1 free body coasting at the reference velocity (closed form, float64)
+        double *g = T.ghost;
+        const double hh = (double)M.h;
+        g[9] += hh * K.ghost_accel_z;
+        g[0] += hh * g[7]; g[1] += hh * g[8]; g[2] += hh * g[9];
+        double n = sqrt(g[10] * g[10] + g[11] * g[11] + g[12] * g[12]);
+        double qn = sqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5] + g[6] * g[6]);
+        double q0 = g[3] / qn, q1 = g[4] / qn, q2 = g[5] / qn, q3 = g[6] / qn;
+        if (n >= 1e-15) {
+          double sh, ch;
+          sincos(0.5 * n * hh, &sh, &ch);
+          double ax = g[10] / n * sh, ay = g[11] / n * sh, az = g[12] / n * sh;
+          double w = q0 * ch - q1 * ax - q2 * ay - q3 * az, x = q0 * ax + q1 * ch + q2 * az - q3 * ay,
+                 y = q0 * ay - q1 * az + q2 * ch + q3 * ax, z = q0 * az + q1 * ay - q2 * ax + q3 * ch;
+          double m = sqrt(w * w + x * x + y * y + z * z);
+          q0 = w / m; q1 = x / m; q2 = y / m; q3 = z / m;
+        }
+        g[3] = q0; g[4] = q1; g[5] = q2; g[6] = q3;
+      }
     }
+    if (do_reset) break;
   }
+  SYNC();
+  V3 s_acc = {T.sens[0], T.sens[1], T.sens[2]}, s_gyro = {T.sens[3], T.sens[4], T.sens[5]}, s_vel = {T.sens[6], T.sens[7], T.sens[8]};
   const float inv = (do_reset && K.pad_first_obs) ? 1.f : 1.f / (float)nsub;
   float cdist;
   Q4 rq0;
-  write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, rootpos, traj_idx, step_counter, cdist, rq0);
+  write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, traj_idx, step_counter, cdist, rq0);
   if (do_reset) {
     if (lane == 0) { reward_out[env] = 0.f; discount_out[env] = 1.f; step_type_out[env] = FFE_STEP_FIRST; S.needs_reset = 0; S.forced_traj = -1; }
   } else {
     // ---- check_termination (ref: flight_imitation.py:198-209, base.py:214-217); qacc is the last substep's
     float qn2 = wave_sum(lane < M.nv ? c.qacc * c.qacc : 0.f);
-    float height = (float)rootpos[2];
+    float height = (float)T.rootpos[2];
     int lim = K.traj_len < K.time_limit_steps ? K.traj_len : K.time_limit_steps;
     int traj_timesteps = lim - (K.future_steps + 1);
     bool reached_end = (step_counter == traj_timesteps);
@@ -898,7 +930,8 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
     // ---- reward (ref: flight_imitation.py:169-196): ghost CoM vs walker CoM, and root orientation error
     if (lane == 0) {
       const double ox = -0.03697732, oy = 0.00029205, oz = -0.0142447;  // ref: task_utils.py:188
-      double w = gq[0], x = gq[1], y = gq[2], z = gq[3];
+      const double *gpos = T.ghost, *rootpos = T.rootpos;
+      double w = T.ghost[3], x = T.ghost[4], y = T.ghost[5], z = T.ghost[6];
       double n2 = w * w + x * x + y * y + z * z;
       double gx = gpos[0] + ((w * w + x * x - y * y - z * z) * ox + 2 * (x * y - w * z) * oy + 2 * (x * z + w * y) * oz) / n2;
       double gy = gpos[1] + (2 * (x * y + w * z) * ox + (w * w - x * x + y * y - z * z) * oy + 2 * (y * z - w * x) * oz) / n2;
@@ -915,15 +948,12 @@ __global__ __launch_bounds__(kWave, 2) void flight_step_kernel(const DevModel *_
       S.needs_reset = (term || time_up) ? 1 : 0;
     }
   }
-  if (lane == 0) {
-    for (int k = 0; k < 3; k++) S.ghost[k] = gpos[k];
-    for (int k = 0; k < 4; k++) S.ghost[3 + k] = gq[k];
-    S.episode = episode;
-  }
+  if (lane < 7) S.ghost[lane] = T.ghost[lane];
+  if (lane == 0) S.episode = episode;
   // ---- store state
   if (lane < kMaxDof + 4) { S.qpos[lane] = T.qpos[lane]; S.qvel[lane] = T.qvel[lane]; }
   if (lane == 0) {
-    S.rootpos[0] = rootpos[0]; S.rootpos[1] = rootpos[1]; S.rootpos[2] = rootpos[2];
+    S.rootpos[0] = T.rootpos[0]; S.rootpos[1] = T.rootpos[1]; S.rootpos[2] = T.rootpos[2];
     S.wb_ctrl_freq = wb_cf; S.wb_step = wb_step; S.wb_freq_idx = wb_idx; S.step_counter = step_counter; S.traj_idx = traj_idx;
     S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.solver_iters = iters;
     S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
