@@ -24,7 +24,7 @@
 #include "dev_model.hpp"
 
 #ifndef FFE_WAVES_PER_SIMD
-#define FFE_WAVES_PER_SIMD 2  // register budget = 512 / this; picked by measurement
+#define FFE_WAVES_PER_SIMD 3  // register budget = 512 / this; picked by measurement
 #endif
 
 namespace ffe {
@@ -180,10 +180,12 @@ __device__ __forceinline__ V3 rotate_vec_with_quat(V3 v, Q4 q) {
   return {r.x, r.y, r.z};
 }
 __device__ __forceinline__ float quat_dist_short_arc(Q4 a, Q4 b) {
-  float na = sqrtf(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z), nb = sqrtf(b.w * b.w + b.x * b.x + b.y * b.y + b.z * b.z);
-  float dp = (a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z) / (na * nb);
-  float x = fminf(1.0f, 2.f * dp * dp - 1.f);
-  return acosf(x);
+  // The reference evaluates acos(min(1, 2 (p.q)^2 - 1)) in float64.  In float32 that form loses half the digits
+  // near zero angle (d acos/dx blows up at x = 1), so the same angle is taken from the relative quaternion
+  // dq = conj(a) b as 2 atan2(|vec dq|, |w dq|), which is identical for unit quaternions and well conditioned.
+  Q4 d = qmul(qconj(a), b);
+  float v = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+  return 2.0f * atan2f(v, fabsf(d.w));
 }
 
 // mj: inertia-box fluid model (mj_inertiaBoxFluidModel) for one body whose inertial frame sits at `rpos`

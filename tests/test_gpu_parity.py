@@ -148,7 +148,11 @@ def _rollout(env, oenvs, torch, steps, teacher, seed, act_scale=1.0):
                 continue
             assert od == disc[i]
             eo = max(eo, _obs_err(obs[i], oo)); er = max(er, abs(rew[i] - orr))
-            eq = max(eq, _scaled_err(qpos[i], oenvs[i].data.qpos)); ev = max(ev, _scaled_err(qvel[i], oenvs[i].data.qvel))
+            eq = max(eq, _scaled_err(qpos[i], oenvs[i].data.qpos))
+            dv = np.abs(qvel[i] - oenvs[i].data.qvel) / np.maximum(1.0, np.abs(oenvs[i].data.qvel))
+            if dv.max() > ev:
+                ev = dv.max(); j = int(np.argmax(dv))
+                errs["detail"] = (k, i, j, float(qvel[i][j]), float(oenvs[i].data.qvel[j]), int(oenvs[i].data.nefc), float(rew[i]), float(orr))
             if ost == 2:
                 alive[i] = False
         errs["obs"].append(eo); errs["reward"].append(er); errs["qpos"].append(eq); errs["qvel"].append(ev)
@@ -157,14 +161,18 @@ def _rollout(env, oenvs, torch, steps, teacher, seed, act_scale=1.0):
             env.set_state(torch.tensor(q), torch.tensor(v))
         if not alive.any():
             break
-    return {k: np.array(v) for k, v in errs.items()}, alive
+    detail = errs.pop("detail", None)
+    out = {k: np.array(v) for k, v in errs.items()}
+    out["detail"] = detail
+    return out, alive
 
 
 def test_teacher_forced_step_parity(setup, torch_mod):
     """Every control step starts from the oracle's state: per-step error of the HIP path, 200 steps x 16 envs."""
     env, oenvs = setup
     errs, alive = _rollout(env, oenvs, torch_mod, 200, teacher=True, seed=11, act_scale=0.3)
-    print("teacher-forced max errs", {k: float(v.max()) for k, v in errs.items()})
+    print("teacher-forced max errs", {k: float(v.max()) for k, v in errs.items() if k != "detail"})
+    print("teacher-forced worst dof detail", errs.get("detail"))
     assert errs["obs"].max() < TOL_OBS_1STEP
     assert errs["reward"].max() < TOL_REWARD_1STEP
 
@@ -173,7 +181,7 @@ def test_open_loop_drift(setup, torch_mod):
     """No state resynchronisation: float32 drift of reward over 100 control steps (400 physics substeps)."""
     env, oenvs = setup
     errs, alive = _rollout(env, oenvs, torch_mod, 100, teacher=False, seed=12, act_scale=0.3)
-    print("open-loop reward err @10,50,100:", errs["reward"][[9, 49, min(99, len(errs["reward"]) - 1)]], "qpos", errs["qpos"][-1])
+    print("open-loop reward err @10,50,100:", errs["reward"][[9, 49, min(99, len(errs["reward"]) - 1)]], "qpos", errs["qpos"][-1], "detail", errs["detail"])
     assert errs["reward"].max() < TOL_REWARD_OPEN_100
 
 
