@@ -22,8 +22,9 @@ def torch_mod():
     return torch
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture()
 def setup(torch_mod, wb_tables, ref_traj):
+    """A fresh HIP env and its 16 float64 oracle twins (same seed, same env ids, same tables)."""
     from flybody_amd.batched_env import BatchedFlyEnv
     from oracle import oracle as O
 
@@ -31,7 +32,8 @@ def setup(torch_mod, wb_tables, ref_traj):
     env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=3)
     om = O.OracleModel(BLOB)
     oenvs = [O.OracleFlightEnv(om, wb_tables, *ref_traj, ghost_accel_z=env.ghost_accel_z, seed=3, env_id=i) for i in range(B)]
-    return env, oenvs
+    yield env, oenvs
+    env.close()
 
 
 def _scaled_err(a, b):
@@ -105,28 +107,35 @@ def test_reset_matches_oracle(setup, torch_mod):
 
 
 def test_counter_rng_matches_oracle(setup, torch_mod):
-    """Without forcing, trajectory index and wing phase come from the shared counter-based generator."""
+    """Without forcing, trajectory index and wing phase come from the shared counter-based generator
+    (splitmix64 keyed by seed, global env id, episode number)."""
     from oracle import oracle as O
 
     env, oenvs = setup
-    env.reset()
-    torch_mod.cuda.synchronize()
-    ints, _ = [x.cpu().numpy() for x in env.get_task_state()]
-    # second episode of this handle (fixture reset once already): episode counters advance per env
-    for i in range(env.batch_size):
-        found = any(ints[i, 3] == O.rng_u64(3, i, ep, 0) % 8 for ep in range(0, 6))
-        assert found
+    for episode in range(3):
+        env.reset()
+        torch_mod.cuda.synchronize()
+        ints, _ = [x.cpu().numpy() for x in env.get_task_state()]
+        obs = env.flat_observation.cpu().numpy().astype(np.float64)
+        for i in range(env.batch_size):
+            assert ints[i, 3] == O.rng_u64(3, i, episode, 0) % 8
+            st, r, d, o = oenvs[i].reset()
+            assert oenvs[i].counters()[0] == ints[i, 3]
+            assert _obs_err(obs[i], o) < TOL_OBS_1STEP
 
 
 def _rollout(env, oenvs, torch, steps, teacher, seed, act_scale=1.0):
+    """Steps both implementations with identical actions.  Episodes end and restart on both sides through the shared
+    counter-based generator; an env whose LAST/MID decision differs (a threshold crossed within float32 rounding) is
+    dropped from the comparison from that step on."""
     B = env.batch_size
     rng = np.random.RandomState(seed)
     amin, amax = env.action_spec().minimum, env.action_spec().maximum
-    traj, phase = rng.randint(0, 8, B), rng.uniform(0, 0.95, B)
-    env.set_next_trajectory_index(traj, phase)
     env.reset()
-    _oracle_reset(oenvs, traj, phase)
+    for e in oenvs:
+        e.reset()
     errs = dict(obs=[], reward=[], qpos=[], qvel=[])
+    stats = dict(compared=0, reward_sum=0.0, reward_pos=0, resets=0, dropped=0, worst=None)
     alive = np.ones(B, bool)
     for k in range(steps):
         a = (amin + (amax - amin) * (0.5 + 0.5 * act_scale * rng.uniform(-1, 1, (B, len(amin))))).astype(np.float32)
@@ -143,45 +152,47 @@ def _rollout(env, oenvs, torch, steps, teacher, seed, act_scale=1.0):
             ws, wi, wc = oenvs[i].wbpg_state()
             assert (ints[i, 0], ints[i, 1]) == (ws, wi) and reals[i, 0] == wc, ("wbpg", k, i)
             if ost != st[i]:
-                # termination decided on a threshold crossing may flip under float32; stop comparing this env
                 alive[i] = False
+                stats["dropped"] += 1
                 continue
             assert od == disc[i]
-            eo = max(eo, _obs_err(obs[i], oo)); er = max(er, abs(rew[i] - orr))
+            stats["compared"] += 1; stats["reward_sum"] += orr; stats["reward_pos"] += int(orr > 0); stats["resets"] += int(ost == 0)
+            eo = max(eo, _obs_err(obs[i], oo))
+            if abs(rew[i] - orr) > er:
+                er = abs(rew[i] - orr)
             eq = max(eq, _scaled_err(qpos[i], oenvs[i].data.qpos))
             dv = np.abs(qvel[i] - oenvs[i].data.qvel) / np.maximum(1.0, np.abs(oenvs[i].data.qvel))
             if dv.max() > ev:
-                ev = dv.max(); j = int(np.argmax(dv))
-                errs["detail"] = (k, i, j, float(qvel[i][j]), float(oenvs[i].data.qvel[j]), int(oenvs[i].data.nefc), float(rew[i]), float(orr))
-            if ost == 2:
-                alive[i] = False
+                ev = dv.max()
+            if stats["worst"] is None or dv.max() > stats["worst"][0]:
+                j = int(np.argmax(dv))
+                stats["worst"] = (float(dv.max()), k, i, j, float(qvel[i][j]), float(oenvs[i].data.qvel[j]), int(oenvs[i].data.nefc))
         errs["obs"].append(eo); errs["reward"].append(er); errs["qpos"].append(eq); errs["qvel"].append(ev)
         if teacher:
             q = np.stack([e.data.qpos for e in oenvs]); v = np.stack([e.data.qvel for e in oenvs])
             env.set_state(torch.tensor(q), torch.tensor(v))
         if not alive.any():
             break
-    detail = errs.pop("detail", None)
-    out = {k: np.array(v) for k, v in errs.items()}
-    out["detail"] = detail
-    return out, alive
+    return {k: np.array(v) for k, v in errs.items()}, stats
 
 
 def test_teacher_forced_step_parity(setup, torch_mod):
-    """Every control step starts from the oracle's state: per-step error of the HIP path, 200 steps x 16 envs."""
+    """Every control step starts from the oracle's state: per-step error of the HIP path over 400 steps x 16 envs,
+    across episode boundaries (so the reward is non-zero for a good share of the compared steps)."""
     env, oenvs = setup
-    errs, alive = _rollout(env, oenvs, torch_mod, 200, teacher=True, seed=11, act_scale=0.3)
-    print("teacher-forced max errs", {k: float(v.max()) for k, v in errs.items() if k != "detail"})
-    print("teacher-forced worst dof detail", errs.get("detail"))
+    errs, stats = _rollout(env, oenvs, torch_mod, 400, teacher=True, seed=11, act_scale=0.3)
+    print("teacher-forced max errs", {k: float(v.max()) for k, v in errs.items()}, stats)
+    assert stats["compared"] > 5000 and stats["reward_pos"] > 1000 and stats["resets"] >= 16
     assert errs["obs"].max() < TOL_OBS_1STEP
     assert errs["reward"].max() < TOL_REWARD_1STEP
 
 
 def test_open_loop_drift(setup, torch_mod):
-    """No state resynchronisation: float32 drift of reward over 100 control steps (400 physics substeps)."""
+    """No state resynchronisation: float32 drift over whole episodes (each ~100 control steps = 400 substeps)."""
     env, oenvs = setup
-    errs, alive = _rollout(env, oenvs, torch_mod, 100, teacher=False, seed=12, act_scale=0.3)
-    print("open-loop reward err @10,50,100:", errs["reward"][[9, 49, min(99, len(errs["reward"]) - 1)]], "qpos", errs["qpos"][-1], "detail", errs["detail"])
+    errs, stats = _rollout(env, oenvs, torch_mod, 300, teacher=False, seed=12, act_scale=0.3)
+    print("open-loop max reward err", float(errs["reward"].max()), "obs", float(errs["obs"].max()), "qpos", float(errs["qpos"].max()), stats)
+    assert stats["reward_pos"] > 500
     assert errs["reward"].max() < TOL_REWARD_OPEN_100
 
 
