@@ -112,7 +112,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B = args.envs_per_gpu
-    env = fly_envs.flight_imitation(batch_size=B, device=local_rank, random_state=0, env_id_base=rank * B)
+    from flybody_amd.distributed import shard
+
+    env_id_base, _ = shard(rank, world, B)
+    env = fly_envs.flight_imitation(batch_size=B, device=local_rank, random_state=0, env_id_base=env_id_base)
     spec = env.action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
     hi = torch.tensor(spec.maximum, device=dev)
@@ -120,18 +123,15 @@ def main():
     npool = 16
     acts = [(lo + (hi - lo) * torch.rand(B, spec.shape[0], device=dev, generator=g)).contiguous() for _ in range(npool)]
 
-    # the per-step gather of everything a central learner consumes
-    pack = torch.empty(B, env.spec.obs_dim + 3, dtype=torch.float32, device=dev)
-    gather_list = [torch.empty_like(pack) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # the per-step gather of everything a central learner consumes: one RCCL call per step
+    from flybody_amd.distributed import TimestepGather
+
+    gather = TimestepGather(B, env.spec.obs_dim, dev, world, rank)
 
     def one_step(k):
         ts = env.step(acts[k % npool])
         if world > 1:
-            pack[:, : env.spec.obs_dim] = env.flat_observation
-            pack[:, -3] = ts.reward
-            pack[:, -2] = ts.discount
-            pack[:, -1] = ts.step_type.to(torch.float32)
-            dist.gather(pack, gather_list, dst=0)
+            gather(env.flat_observation, ts.reward, ts.discount, ts.step_type)
         return ts
 
     env.reset()
