@@ -76,7 +76,8 @@ struct DevModel {
   int nlink, nv, nq, nu, nM, ntri, nrootrec, nobsj, nwing, naction, maxdepth, nsub;
   float h, gx, gy, gz, total_mass;
   // per dof
-  const int *d_parent, *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id;  // d_act_id: [2][64]
+  const int *d_parent, *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id, *d_ndesc;  // d_act_id: [2][64]
+  const unsigned int *pairtab;  // [256] elimination pairs (s | t << 8), sorted by t then s
   const float *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
       *d_act_coef;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
   // per link
@@ -153,7 +154,7 @@ struct HostModel {
       p = reinterpret_cast<P>(base + reinterpret_cast<size_t>(p));
     };
     fix(dst.d_parent); fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
-    fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
+    fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
     fix(dst.d_sref); fix(dst.d_lo); fix(dst.d_hi); fix(dst.d_margin); fix(dst.d_invw); fix(dst.d_K); fix(dst.d_B);
     fix(dst.d_solimp); fix(dst.d_act_coef);
     fix(dst.l_parent); fix(dst.l_dofadr); fix(dst.l_dofnum); fix(dst.l_sub); fix(dst.l_reckind); fix(dst.l_recell);
@@ -251,6 +252,23 @@ inline HostModel build_host_model(const Blob &b) {
     d_depth[d] = depth;
     maxdepth = depth > maxdepth ? depth : maxdepth;
   }
+  // descendants of a dof are the contiguous index range that follows it (bodies and dofs are in depth-first order)
+  auto d_ndesc = lane_i(1);
+  for (int d = 0; d < nv; d++)
+    for (int a = dofpar.i(d); a >= 0; a = dofpar.i(a)) d_ndesc[a]++;
+  for (int d = 0; d < nv; d++)
+    for (int e = d + 1; e <= d + d_ndesc[d]; e++) {
+      bool ok = false;
+      for (int a = dofpar.i(e); a >= 0; a = dofpar.i(a)) ok |= (a == d);
+      if (!ok) throw std::runtime_error("dof tree is not in depth-first order");
+    }
+  std::vector<unsigned int> pairtab(4 * kWave, 0xffffu);
+  {
+    int p = 0;
+    for (int t = 1; t <= 22 && p < 4 * kWave; t++)
+      for (int sidx = 1; sidx <= t && p < 4 * kWave; sidx++) pairtab[p++] = static_cast<unsigned>(sidx) | (static_cast<unsigned>(t) << 8);
+  }
+  if ((maxdepth - 1) * maxdepth / 2 > 4 * kWave) throw std::runtime_error("dof chains too deep for the pair table");
   const int nM = static_cast<int>(m_row.size());
   if (nM > kMaxM) throw std::runtime_error("mass matrix exceeds kernel capacity");
   V.nM = nM; V.maxdepth = maxdepth;
@@ -410,6 +428,7 @@ inline HostModel build_host_model(const Blob &b) {
   V.d_madr = FFE_OFF(const int *, A.put(d_madr)); V.d_depth = FFE_OFF(const int *, A.put(d_depth));
   V.d_kind = FFE_OFF(const int *, A.put(d_kind)); V.d_qadr = FFE_OFF(const int *, A.put(d_qadr));
   V.d_limited = FFE_OFF(const int *, A.put(d_limited)); V.d_act_id = FFE_OFF(const int *, A.put(d_act_id));
+  V.d_ndesc = FFE_OFF(const int *, A.put(d_ndesc)); V.pairtab = FFE_OFF(const unsigned int *, A.put(pairtab));
   V.d_axis = FFE_OFF(const float *, A.put(d_axis)); V.d_arm = FFE_OFF(const float *, A.put(d_arm));
   V.d_damp = FFE_OFF(const float *, A.put(d_damp)); V.d_stiff = FFE_OFF(const float *, A.put(d_stiff));
   V.d_sref = FFE_OFF(const float *, A.put(d_sref)); V.d_lo = FFE_OFF(const float *, A.put(d_lo));

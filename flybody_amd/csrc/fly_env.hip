@@ -70,10 +70,11 @@ struct alignas(16) Tile {
   float lb[kMaxLink][6];
   float lc[kMaxLink][6];
   float M[kMaxM];
-  float LD[kMaxM];
+  float2 LD[kMaxM];           // two factorisations side by side: .x = constraint Hessian, .y = M + h B (Euler)
   float dinv[kLanePad];
   float x[kLanePad];
   float frc[kMaxAct];
+  unsigned short colmadr[kMaxM + 8];  // for entry e = (row k, column a): start of row a in M/LD
   float sens[12];    // running sums of the buffered sensors: acc[3], gyro[3], vel[3]
   double rootpos[4];  // free-joint position in float64
   double ghost[16];   // pos[3], quat[4], vel[3], angvel[3]
@@ -269,13 +270,29 @@ struct Ctx {
   // per-link registers
   int l_par, l_dofadr, l_dofnum, l_sub;
   int lanc[8];  // ancestor chain of this lane's link, nearest first (-1 terminated)
+  int d_ndesc;       // number of descendant dofs (they are the contiguous range lane+1 .. lane+d_ndesc)
+  int pair_s[4], pair_t[4]; // this lane's elimination pairs (s, t) for p = lane + 64 r in the t-major enumeration
+  float dinv[2];     // 1 / D of this lane's dof for the two resident factorisations
   V3 com;       // subtree CoM of the whole fly, root-relative
   // outputs of stage 1 kept per dof lane
   float f_smooth_nb;  // passive(spring+damper) - bias + fluid  (actuation is added in stage 2)
   float qacc;         // constrained acceleration (mj: d->qacc)
 };
 
+// One workgroup = one wavefront, and a wavefront's LDS operations execute in issue order, so making one lane's LDS
+// write visible to another lane needs no hardware wait at all - only the compiler must not reorder across the point.
+#if defined(FFE_HW_SYNC)
 #define SYNC() __syncthreads()
+#else
+#define SYNC()                                                   \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+  } while (0)
+#endif
+// timing-only ablation switches (bench experiments; results are wrong when set)
+enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22 };
 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
@@ -468,6 +485,7 @@ __device__ void stage1(Ctx &c) {
   }
   SYNC();
   // ---- mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs
+  if (!(c.flags & DBG_SKIP_MENTRIES))
   for (int e = lane; e < M.nM; e += kWave) {
     int i = M.m_row[e], j = M.m_col[e];
     float v = dot6(ld6(T.cdof[j]), ld6(T.buf[i]));
@@ -477,64 +495,133 @@ __device__ void stage1(Ctx &c) {
   SYNC();
 }
 
-// mj: mj_factorI on (M + diag(add)); rows are left unscaled and 1/D kept aside (T.dinv).
-__device__ void factor(Ctx &c, float add) {
+__device__ __forceinline__ int rl_i(int v, int lane_idx) { return __builtin_amdgcn_readlane(v, lane_idx); }
+__device__ __forceinline__ float rl_f(float v, int lane_idx) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx)); }
+
+// mj: mj_factorI on (M + diag(add)).  Tree-sparse L'DL in MuJoCo's row layout (row i = [M(i,i), M(i,parent), ...]);
+// rows are left unscaled and 1/D is kept per lane (c.dinv).  Pivots run leaf -> root; pivot k with n ancestors
+// a_1..a_n applies M(a_s,a_t) -= M(k,a_s) M(k,a_t) / M(k,k) for s <= t.  Lanes own (s,t) pairs in an enumeration
+// sorted by t, so the pairs of any pivot are a prefix and live in registers for the whole kernel; every address is
+// arithmetic or an LDS lookup - no global memory inside the dependent chain.
+// A substep needs two factorisations of the same sparsity that differ only in their diagonals (the constraint Hessian
+// M + D_active and the implicit-damping matrix M + h B).  DUAL factors both in one sweep: entries are float2, so the
+// LDS instruction count and all index arithmetic are those of a single factorisation.  Non-DUAL refactors slot .x only
+// (an active-set change) and leaves the Euler factor in .y untouched.
+template <bool DUAL>
+__device__ void factor(Ctx &c, float add0, float add1) {
   const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
-  for (int e = lane; e < M.nM; e += kWave) T.LD[e] = T.M[e];
+  const int nv = M.nv;
+  if (c.flags & DBG_SKIP_FACTOR) {
+    c.dinv[0] = lane < nv ? 1.0f / (T.M[c.d_madr] + add0) : 0.f;
+    if (DUAL) c.dinv[1] = lane < nv ? 1.0f / (T.M[c.d_madr] + add1) : 0.f;
+    return;
+  }
+  for (int e = lane; e < M.nM; e += kWave) {
+    const float m = T.M[e];
+    if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
+  }
   SYNC();
-  if (lane < M.nv) T.LD[c.d_madr] += add;
+  if (lane < nv) {
+    T.LD[c.d_madr].x += add0;
+    if (DUAL) T.LD[c.d_madr].y += add1;
+  }
   SYNC();
-  for (int k = M.nv - 1; k > 0; k--) {
-    const int base = M.tri_off[k], cnt = M.tri_off[k + 1] - base;
-    if (cnt == 0) continue;
-    const int mk = M.d_madr[k];
-    const float invD = 1.0f / T.LD[mk];
-    for (int p = lane; p < cnt; p += kWave) {
-      unsigned t = M.tri[base + p];
-      int tgt = t >> 16, s = (t >> 8) & 0xff, u = t & 0xff;
-      T.LD[tgt] -= T.LD[mk + s] * invD * T.LD[mk + u];
+#pragma unroll 1
+  for (int k = nv - 1; k > 0; k--) {
+    const int n = rl_i(c.d_depth, k) - 1;
+    const int mk = rl_i(c.d_madr, k);
+    const int cnt = (n * (n + 1)) >> 1;
+    float2 piv;
+    if (DUAL) piv = T.LD[mk]; else piv.x = T.LD[mk].x;
+    const float inv0 = __builtin_amdgcn_rcpf(piv.x);
+    const float inv1 = DUAL ? __builtin_amdgcn_rcpf(piv.y) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (r * kWave < cnt) {  // wave-uniform
+        if (lane + r * kWave < cnt) {
+          const int sidx = c.pair_s[r], tidx = c.pair_t[r];
+          const int tgt = (int)T.colmadr[mk + sidx] + (tidx - sidx);
+          if (DUAL) {
+            const float2 a = T.LD[mk + sidx], b = T.LD[mk + tidx];
+            float2 t = T.LD[tgt];
+            t.x -= a.x * inv0 * b.x;
+            t.y -= a.y * inv1 * b.y;
+            T.LD[tgt] = t;
+          } else {
+            T.LD[tgt].x -= T.LD[mk + sidx].x * inv0 * T.LD[mk + tidx].x;
+          }
+        }
+      }
     }
     SYNC();
   }
-  if (lane < M.nv) T.dinv[lane] = 1.0f / T.LD[c.d_madr];
-  SYNC();
+  if (DUAL) {
+    const float2 d = T.LD[c.d_madr];
+    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(d.x) : 0.f;
+    c.dinv[1] = lane < nv ? __builtin_amdgcn_rcpf(d.y) : 0.f;
+  } else {
+    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(T.LD[c.d_madr].x) : 0.f;
+  }
 }
 
-// mj: mj_solveLD with the factor above.  `rhs` per dof lane in, solution per dof lane out.
+// mj: mj_solveLD with the factor above; the vector lives in registers (one dof per lane) and travels by readlane,
+// the factor is only read, so there is no barrier inside the two sweeps.
+template <int COMP>
 __device__ float solve(Ctx &c, float rhs) {
   const DevModel &M = *c.Mp;
   Tile &T = c.T;
   const int lane = c.lane;
-  const bool is_dof = lane < M.nv;
-  if (is_dof) T.x[lane] = rhs;
-  SYNC();
-  // x <- L^-T x : pivots from the leaves to the root, each scattering to its ancestors
-  for (int i = M.nv - 1; i > 0; i--) {
-    const int n = M.d_depth[i] - 1;
-    if (n == 0) continue;
-    const int mi = M.d_madr[i];
-    if (lane < n) {
-      int a = M.m_col[mi + 1 + lane];
-      T.x[a] -= T.LD[mi + 1 + lane] * T.dinv[i] * T.x[i];
-    }
-    SYNC();
+  const int nv = M.nv;
+  const bool is_dof = lane < nv;
+  const float dinv = c.dinv[COMP];
+  const float *LDc = reinterpret_cast<const float *>(T.LD) + COMP;  // entry e of this factor sits at LDc[2 e]
+  if (c.flags & DBG_SKIP_SOLVE) return is_dof ? rhs * dinv : 0.f;
+  float x = is_dof ? rhs : 0.f;
+  const int my_end = lane + c.d_ndesc;         // last descendant dof of this lane
+  const int my_md = c.d_madr + c.d_depth;      // so that row-entry addresses become (my_md - depth_of_column)
+  const int dep = c.d_depth;
+  // x <- L^-T x : pivots from the leaves to the root; the ancestors of i (lanes j with j < i <= j + ndesc_j) fold it
+  // in.  The factor entries do not depend on x, so they are fetched four pivots ahead of the dependent chain.
+  int i = nv - 1;
+#pragma unroll 1
+  for (; i >= 4; i -= 4) {
+    const bool p0 = lane < i && i <= my_end, p1 = lane < i - 1 && i - 1 <= my_end, p2 = lane < i - 2 && i - 2 <= my_end,
+               p3 = lane < i - 3 && i - 3 <= my_end;
+    const float l0 = p0 ? LDc[2 * (rl_i(my_md, i) - dep)] : 0.f, l1 = p1 ? LDc[2 * (rl_i(my_md, i - 1) - dep)] : 0.f,
+                l2 = p2 ? LDc[2 * (rl_i(my_md, i - 2) - dep)] : 0.f, l3 = p3 ? LDc[2 * (rl_i(my_md, i - 3) - dep)] : 0.f;
+    x -= l0 * (rl_f(x, i) * rl_f(dinv, i));
+    x -= l1 * (rl_f(x, i - 1) * rl_f(dinv, i - 1));
+    x -= l2 * (rl_f(x, i - 2) * rl_f(dinv, i - 2));
+    x -= l3 * (rl_f(x, i - 3) * rl_f(dinv, i - 3));
   }
-  // x <- D^-1 x ; x <- L^-1 x : level by level from the root, every deeper dof folding in one ancestor per level
-  float acc = 0.f, di = 0.f;
-  if (is_dof) { di = T.dinv[lane]; acc = T.x[lane] * di; }
-  SYNC();
-  for (int lvl = 1; lvl <= M.maxdepth; lvl++) {
-    if (is_dof && c.d_depth == lvl) T.x[lane] = acc;
-    SYNC();
-    if (is_dof && c.d_depth > lvl) {
-      int t = c.d_depth - lvl;
-      acc -= T.LD[c.d_madr + t] * di * T.x[M.m_col[c.d_madr + t]];
-    }
+#pragma unroll 1
+  for (; i > 0; i--) {
+    const float l0 = (lane < i && i <= my_end) ? LDc[2 * (rl_i(my_md, i) - dep)] : 0.f;
+    x -= l0 * (rl_f(x, i) * rl_f(dinv, i));
   }
-  SYNC();
-  return acc;
+  // x <- D^-1 x
+  x *= dinv;
+  // x <- L^-1 x : from the root down; every descendant i of j (j < i <= j + ndesc_j) subtracts L(i,j) x_j
+  int j = 0;
+#pragma unroll 1
+  for (; j + 4 <= nv - 1; j += 4) {
+    const bool p0 = lane > j && lane <= rl_i(my_end, j), p1 = lane > j + 1 && lane <= rl_i(my_end, j + 1),
+               p2 = lane > j + 2 && lane <= rl_i(my_end, j + 2), p3 = lane > j + 3 && lane <= rl_i(my_end, j + 3);
+    const float l0 = p0 ? LDc[2 * (my_md - rl_i(dep, j))] * dinv : 0.f, l1 = p1 ? LDc[2 * (my_md - rl_i(dep, j + 1))] * dinv : 0.f,
+                l2 = p2 ? LDc[2 * (my_md - rl_i(dep, j + 2))] * dinv : 0.f, l3 = p3 ? LDc[2 * (my_md - rl_i(dep, j + 3))] * dinv : 0.f;
+    x -= l0 * rl_f(x, j);
+    x -= l1 * rl_f(x, j + 1);
+    x -= l2 * rl_f(x, j + 2);
+    x -= l3 * rl_f(x, j + 3);
+  }
+#pragma unroll 1
+  for (; j < nv - 1; j++) {
+    const float l0 = (lane > j && lane <= rl_i(my_end, j)) ? LDc[2 * (my_md - rl_i(dep, j))] * dinv : 0.f;
+    x -= l0 * rl_f(x, j);
+  }
+  return x;
 }
 
 struct StepOut {
@@ -583,34 +670,25 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
   bool act_lo = ex_lo, act_hi = ex_hi;  // first guess: an instantiated limit is active
   float a = 0.f, ae = 0.f, fc = 0.f;
   int iters = 0;
-  bool euler_phase = false;
   const bool want_euler = integrate && !(c.flags & FFE_NO_DAMPER);
+  const float hB = (is_dof && want_euler) ? h * M.d_damp[lane] : 0.f;
 #pragma unroll 1
-  for (int it = 0; it < 10; it++) {
-    float add, rhs;
-    if (!euler_phase) {
-      add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
-      rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
-    } else {
-      add = is_dof ? h * M.d_damp[lane] : 0.f;
-      rhs = f + fc;
-    }
-    factor(c, add);
-    float x = solve(c, rhs);
-    if (euler_phase) { ae = x; break; }
-    a = x;
+  for (int it = 0; it < 8; it++) {
+    const float add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
+    const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
+    if (it == 0) factor<true>(c, add, hB);   // constraint Hessian and Euler matrix in one sweep
+    else factor<false>(c, add, 0.f);          // active set changed: refactor the Hessian only
+    a = solve<0>(c, rhs);
     iters++;
-    bool n_lo = ex_lo && (a - ar_lo < 0.f);
-    bool n_hi = ex_hi && (-a - ar_hi < 0.f);
-    bool changed = (n_lo != act_lo) || (n_hi != act_hi);
+    const bool n_lo = ex_lo && (a - ar_lo < 0.f);
+    const bool n_hi = ex_hi && (-a - ar_hi < 0.f);
+    const bool changed = (n_lo != act_lo) || (n_hi != act_hi);
     act_lo = n_lo; act_hi = n_hi;
-    if (ex_any == 0ULL || __ballot(changed) == 0ULL || it >= 6) {
-      if (act_lo) fc += D_lo * (ar_lo - a);
-      if (act_hi) fc -= D_hi * (ar_hi + a);
-      if (!want_euler) { ae = a; break; }
-      euler_phase = true;
-    }
+    if (ex_any == 0ULL || __ballot(changed) == 0ULL) break;
   }
+  if (act_lo) fc += D_lo * (ar_lo - a);
+  if (act_hi) fc -= D_hi * (ar_hi + a);
+  ae = want_euler ? solve<1>(c, f + fc) : a;
   lo_mask = __ballot(act_lo);
   hi_mask = __ballot(act_hi);
   iters_out = ex_any ? iters : 0;
@@ -757,6 +835,11 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
     c.lanc[it] = a;
     a = a >= 0 ? M.l_parent[a] : -1;
   }
+  c.d_ndesc = M.d_ndesc[lane];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { unsigned pr = M.pairtab[lane + r * kWave]; c.pair_s[r] = pr & 0xff; c.pair_t[r] = pr >> 8; }
+  c.dinv[0] = c.dinv[1] = 0.f;
+  for (int e = lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
 }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
@@ -831,7 +914,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
       wb_step = (wb_step + 1) % len;
       wb_cf = wbpg_filter(wb_cf, K.rate, K.base_freq, K.rel_range, (double)act_user);
-      int idx_new = wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane);
+      int idx_new = (c.flags & DBG_SKIP_WBPG) ? wb_idx : wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane);
       if (idx_new != wb_idx) {
         double cur = K.phase_frac[off + wb_step];
         int noff = K.tab_off[idx_new], nlen = K.tab_off[idx_new + 1] - noff;
@@ -871,7 +954,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       asm volatile("" : "+s"(ml));
       c.Mp = ml;
     }
-    stage1(c);
+    if (!(c.flags & DBG_SKIP_STAGE1) || s == 0) stage1(c);
     if (lane == 0 && (do_reset || s > 0)) {
       V3 v = mtv(ldm(T.xmat[0]), V3{T.qvel[0], T.qvel[1], T.qvel[2]});
       T.sens[3] += T.qvel[3]; T.sens[4] += T.qvel[4]; T.sens[5] += T.qvel[5];
@@ -889,24 +972,18 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     iters += it;
     if (lane == 0) {
       T.sens[0] += acc.x; T.sens[1] += acc.y; T.sens[2] += acc.z;
-      if (!do_reset) {
+      if (!do_reset && !(c.flags & DBG_SKIP_GHOST)) {
         // ghost: armature-1 free body coasting at the reference velocity (closed form, float64)
         double *g = T.ghost;
         const double hh = (double)M.h;
         g[9] += hh * K.ghost_accel_z;
         g[0] += hh * g[7]; g[1] += hh * g[8]; g[2] += hh * g[9];
-        double n = sqrt(g[10] * g[10] + g[11] * g[11] + g[12] * g[12]);
-        double qn = sqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5] + g[6] * g[6]);
-        double q0 = g[3] / qn, q1 = g[4] / qn, q2 = g[5] / qn, q3 = g[6] / qn;
-        if (n >= 1e-15) {
-          double sh, ch;
-          sincos(0.5 * n * hh, &sh, &ch);
-          double ax = g[10] / n * sh, ay = g[11] / n * sh, az = g[12] / n * sh;
-          double w = q0 * ch - q1 * ax - q2 * ay - q3 * az, x = q0 * ax + q1 * ch + q2 * az - q3 * ay,
-                 y = q0 * ay - q1 * az + q2 * ch + q3 * ax, z = q0 * az + q1 * ay - q2 * ax + q3 * ch;
-          double m = sqrt(w * w + x * x + y * y + z * z);
-          q0 = w / m; q1 = x / m; q2 = y / m; q3 = z / m;
-        }
+        // orientation in float32: it only steers the 0.04 cm root->CoM lever of the tracking reward
+        V3 gw = {(float)g[10], (float)g[11], (float)g[12]};
+        float gn = sqrtf(dot(gw, gw));
+        Q4 gq = qnormalize(Q4{(float)g[3], (float)g[4], (float)g[5], (float)g[6]});
+        if (gn >= 1e-15f) gq = qnormalize(qmul(gq, axis_angle((1.0f / gn) * gw, gn * M.h)));
+        double q0 = gq.w, q1 = gq.x, q2 = gq.y, q3 = gq.z;
         g[3] = q0; g[4] = q1; g[5] = q2; g[6] = q3;
       }
     }
@@ -917,7 +994,8 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   const float inv = (do_reset && K.pad_first_obs) ? 1.f : 1.f / (float)nsub;
   float cdist;
   Q4 rq0;
-  write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, traj_idx, step_counter, cdist, rq0);
+  if (c.flags & DBG_SKIP_OBS) { cdist = 0.f; rq0 = {1.f, 0.f, 0.f, 0.f}; }
+  else write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, traj_idx, step_counter, cdist, rq0);
   if (do_reset) {
     if (lane == 0) { reward_out[env] = 0.f; discount_out[env] = 1.f; step_type_out[env] = FFE_STEP_FIRST; S.needs_reset = 0; S.forced_traj = -1; }
   } else {
