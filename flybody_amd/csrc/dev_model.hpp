@@ -82,6 +82,7 @@ struct DevModel {
       *d_act_coef;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
   // per link
   const int *l_parent, *l_dofadr, *l_dofnum, *l_sub, *l_reckind, *l_recell;
+  const unsigned int *l_anc;  // [2][64] ancestor links packed as bytes, nearest first, 0xff = none
   const float *l_pos, *l_quat, *l_ipos, *l_imat, *l_inertia, *l_mass, *l_recpos, *l_recmat, *l_reccoef;
   // fluid records on the root link, one per lane
   const float *rr_pos, *rr_mat, *rr_coef;
@@ -157,7 +158,7 @@ struct HostModel {
     fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
     fix(dst.d_sref); fix(dst.d_lo); fix(dst.d_hi); fix(dst.d_margin); fix(dst.d_invw); fix(dst.d_K); fix(dst.d_B);
     fix(dst.d_solimp); fix(dst.d_act_coef);
-    fix(dst.l_parent); fix(dst.l_dofadr); fix(dst.l_dofnum); fix(dst.l_sub); fix(dst.l_reckind); fix(dst.l_recell);
+    fix(dst.l_anc); fix(dst.l_parent); fix(dst.l_dofadr); fix(dst.l_dofnum); fix(dst.l_sub); fix(dst.l_reckind); fix(dst.l_recell);
     fix(dst.l_pos); fix(dst.l_quat); fix(dst.l_ipos); fix(dst.l_imat); fix(dst.l_inertia); fix(dst.l_mass);
     fix(dst.l_recpos); fix(dst.l_recmat); fix(dst.l_reccoef);
     fix(dst.rr_pos); fix(dst.rr_mat); fix(dst.rr_coef); fix(dst.ell);
@@ -312,6 +313,18 @@ inline HostModel build_host_model(const Blob &b) {
     total_mass += b.get("link_mass").f(k);
   }
   V.total_mass = static_cast<float>(total_mass);
+  std::vector<unsigned int> l_anc(2 * kLanePad, 0xffffffffu);
+  for (int k = 0; k < nl; k++) {
+    int a = lparent.i(k), it = 0;
+    unsigned long long packed = ~0ULL;
+    while (a >= 0) {
+      if (it >= 8) throw std::runtime_error("link tree deeper than 8 ancestors");
+      packed = (packed & ~(0xffULL << (8 * it))) | (static_cast<unsigned long long>(a) << (8 * it));
+      a = lparent.i(a); it++;
+    }
+    l_anc[k] = static_cast<unsigned int>(packed & 0xffffffffu);
+    l_anc[kLanePad + k] = static_cast<unsigned int>(packed >> 32);
+  }
   // fluid records: root link's go one per lane, every other link carries at most one record of its own
   auto rr_pos = lane_f(3), rr_mat = lane_f(9), rr_coef = lane_f(8);
   int nrr = 0;
@@ -436,6 +449,7 @@ inline HostModel build_host_model(const Blob &b) {
   V.d_invw = FFE_OFF(const float *, A.put(d_invw)); V.d_K = FFE_OFF(const float *, A.put(d_K));
   V.d_B = FFE_OFF(const float *, A.put(d_B)); V.d_solimp = FFE_OFF(const float *, A.put(d_solimp));
   V.d_act_coef = FFE_OFF(const float *, A.put(d_act_coef));
+  V.l_anc = FFE_OFF(const unsigned int *, A.put(l_anc));
   V.l_parent = FFE_OFF(const int *, A.put(l_parent)); V.l_dofadr = FFE_OFF(const int *, A.put(l_dofadr));
   V.l_dofnum = FFE_OFF(const int *, A.put(l_dofnum)); V.l_sub = FFE_OFF(const int *, A.put(l_sub));
   V.l_reckind = FFE_OFF(const int *, A.put(l_reckind)); V.l_recell = FFE_OFF(const int *, A.put(l_recell));

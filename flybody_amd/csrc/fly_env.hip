@@ -97,9 +97,10 @@ __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
 }
 __device__ __forceinline__ Q4 qconj(Q4 q) { return {q.w, -q.x, -q.y, -q.z}; }
 __device__ __forceinline__ Q4 qnormalize(Q4 q) {
-  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  if (n < 1e-15f) return {1.f, 0.f, 0.f, 0.f};
-  float r = 1.0f / n;
+  float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  if (n2 < 1e-30f) return {1.f, 0.f, 0.f, 0.f};
+  float r = __builtin_amdgcn_rsqf(n2);
+  r = r * (1.5f - 0.5f * n2 * r * r);  // one Newton step: full float32 accuracy
   return {q.w * r, q.x * r, q.y * r, q.z * r};
 }
 __device__ __forceinline__ M3 q2m(Q4 q) {
@@ -164,10 +165,20 @@ __device__ __forceinline__ S6 mul_inert(const I10 &i, S6 v) {
           i.i4 * v.a0 + i.i5 * v.a1 + i.i2 * v.a2 - i.i7 * v.l0 + i.i6 * v.l1, i.i8 * v.a1 - i.i7 * v.a2 + i.i9 * v.l0,
           i.i6 * v.a2 - i.i8 * v.a0 + i.i9 * v.l1, i.i7 * v.a0 - i.i6 * v.a1 + i.i9 * v.l2};
 }
+__device__ __forceinline__ int rl_i(int v, int lane_idx) { return __builtin_amdgcn_readlane(v, lane_idx); }
+__device__ __forceinline__ float rl_f(float v, int lane_idx) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx)); }
+// Full-wave sum, result in every lane.  Four DPP steps fold each row of 16 lanes (quad swaps, half-row mirror, row
+// mirror), then the four row totals are read with v_readlane: no LDS traffic, ~11 instructions.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
 }
 __device__ __forceinline__ S6 wave_sum6(S6 s) { return {wave_sum(s.a0), wave_sum(s.a1), wave_sum(s.a2), wave_sum(s.l0), wave_sum(s.l1), wave_sum(s.l2)}; }
 
@@ -189,29 +200,23 @@ __device__ __forceinline__ float quat_dist_short_arc(Q4 a, Q4 b) {
   return 2.0f * atan2f(v, fabsf(d.w));
 }
 
-// mj: inertia-box fluid model (mj_inertiaBoxFluidModel) for one body whose inertial frame sits at `rpos`
-// (link coordinates) with axes `rmat` (link coordinates).  Returns the wrench about the com reference point.
-__device__ __forceinline__ S6 box_fluid(const float *coef, int lane, V3 rpos, const M3 &rmat, V3 xpos, const M3 &xmat, S6 cvel, V3 com) {
-  V3 p = xpos + mv(xmat, rpos);
-  M3 R = mm(xmat, rmat);
-  V3 dif = p - com;
-  V3 w = ang(cvel), v = lin(cvel) - cross(dif, w);
-  V3 lw = mtv(R, w), lv = mtv(R, v);
+// mj: inertia-box fluid model (mj_inertiaBoxFluidModel) for one body whose inertial frame sits at `rpos` with axes
+// `rmat`, both in the coordinates of the link that carries it.  (w_b, v_b) = the link's angular velocity and the linear
+// velocity of the link origin, in link axes.  Returns (torque about the link origin, force) in link axes, so the
+// bodies welded to one link can be summed before a single rotation to the world.
+__device__ __forceinline__ S6 box_fluid_local(const float *coef, int lane, V3 rpos, const M3 &rmat, V3 w_b, V3 v_b) {
+  V3 lw = mtv(rmat, w_b), lv = mtv(rmat, v_b + cross(w_b, rpos));
   float c0 = coef[0 * kLanePad + lane], c1 = coef[1 * kLanePad + lane];
   V3 lt = {-c0 * lw.x - coef[5 * kLanePad + lane] * fabsf(lw.x) * lw.x, -c0 * lw.y - coef[6 * kLanePad + lane] * fabsf(lw.y) * lw.y,
            -c0 * lw.z - coef[7 * kLanePad + lane] * fabsf(lw.z) * lw.z};
   V3 lf = {-c1 * lv.x - coef[2 * kLanePad + lane] * fabsf(lv.x) * lv.x, -c1 * lv.y - coef[3 * kLanePad + lane] * fabsf(lv.y) * lv.y,
            -c1 * lv.z - coef[4 * kLanePad + lane] * fabsf(lv.z) * lv.z};
-  V3 t = mv(R, lt), f = mv(R, lf);
-  return mk6(t + cross(dif, f), f);
+  V3 f = mv(rmat, lf);
+  return mk6(mv(rmat, lt) + cross(rpos, f), f);
 }
-// mj: ellipsoid fluid model (mj_ellipsoidFluidModel + mj_addedMassForces + mj_viscousForces)
-__device__ __forceinline__ S6 ell_fluid(const float *e, V3 rpos, const M3 &rmat, V3 xpos, const M3 &xmat, S6 cvel, V3 com) {
-  V3 p = xpos + mv(xmat, rpos);
-  M3 R = mm(xmat, rmat);
-  V3 dif = p - com;
-  V3 ww = ang(cvel), vv = lin(cvel) - cross(dif, ww);
-  V3 w = mtv(R, ww), v = mtv(R, vv);
+// mj: ellipsoid fluid model (mj_ellipsoidFluidModel + mj_addedMassForces + mj_viscousForces), same conventions
+__device__ __forceinline__ S6 ell_fluid_local(const float *e, V3 rpos, const M3 &rmat, V3 w_b, V3 v_b) {
+  V3 w = mtv(rmat, w_b), v = mtv(rmat, v_b + cross(w_b, rpos));
   V3 plin = {e[1] * v.x, e[2] * v.y, e[3] * v.z}, pang = {e[4] * w.x, e[5] * w.y, e[6] * w.z};
   V3 f = cross(plin, w);
   V3 t = cross(plin, v) + cross(pang, w);
@@ -232,8 +237,8 @@ __device__ __forceinline__ S6 ell_fluid(const float *e, V3 rpos, const M3 &rmat,
   t = t - drag_ang * w;
   f = f - drag_lin * v;
   t = e[0] * t; f = e[0] * f;
-  V3 tw = mv(R, t), fw = mv(R, f);
-  return mk6(tw + cross(dif, fw), fw);
+  V3 fb = mv(rmat, f);
+  return mk6(mv(rmat, t) + cross(rpos, fb), fb);
 }
 
 // mj: getimpedance
@@ -265,19 +270,20 @@ struct Ctx {
   Tile &T;
   int lane;
   int flags;
-  // per-dof registers
-  int d_link, d_kind, d_madr, d_depth, d_parent;
-  // per-link registers
-  int l_par, l_dofadr, l_dofnum, l_sub;
-  int lanc[8];  // ancestor chain of this lane's link, nearest first (-1 terminated)
-  int d_ndesc;       // number of descendant dofs (they are the contiguous range lane+1 .. lane+d_ndesc)
-  int pair_s[4], pair_t[4]; // this lane's elimination pairs (s, t) for p = lane + 64 r in the t-major enumeration
-  float dinv[2];     // 1 / D of this lane's dof for the two resident factorisations
-  V3 com;       // subtree CoM of the whole fly, root-relative
-  // outputs of stage 1 kept per dof lane
-  float f_smooth_nb;  // passive(spring+damper) - bias + fluid  (actuation is added in stage 2)
+  V3 com;             // subtree CoM of the whole fly, root-relative (stage 1 -> reward)
+  float f_smooth_nb;  // passive(spring+damper) - bias + fluid per dof lane (actuation is added in stage 2)
   float qacc;         // constrained acceleration (mj: d->qacc)
+  float dinv[2];      // 1 / D of this lane's dof for the two resident factorisations
 };
+
+// Per-lane model constants are (re)read from the lane-major tables where they are used instead of being pinned in
+// registers across the whole step: the tables are L1/L2 resident, the reads coalesce, and the register allocator is
+// left with short live ranges in the dependent loops.  The pointer is laundered so the loads are not hoisted back.
+__device__ __forceinline__ const DevModel &model(const Ctx &c) {
+  const DevModel *m = c.Mp;
+  asm volatile("" : "+s"(m));
+  return *m;
+}
 
 // One workgroup = one wavefront, and a wavefront's LDS operations execute in issue order, so making one lane's LDS
 // write visible to another lane needs no hardware wait at all - only the compiler must not reorder across the point.
@@ -297,10 +303,13 @@ enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
 __device__ void stage1(Ctx &c) {
-  const DevModel &M = *c.Mp;
+  const DevModel &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_link = lane < M.nlink, is_dof = lane < M.nv;
+  const int l_dofadr = M.l_dofadr[lane], l_dofnum = M.l_dofnum[lane], l_sub = M.l_sub[lane];
+  const int d_link = M.d_link[lane], d_kind = M.d_kind[lane];
+  const unsigned anc_lo = M.l_anc[lane], anc_hi = M.l_anc[kLanePad + lane];  // ancestor links, nearest first, 0xff = none
 
   // ---- K1: link frame in its parent (joint rotations folded in) + hinge axes in the final link frame
   if (is_link) {
@@ -311,8 +320,8 @@ __device__ void stage1(Ctx &c) {
       p = {0.f, 0.f, 0.f};
     } else {
       Q4 qr = {1.f, 0.f, 0.f, 0.f};
-      for (int j = c.l_dofnum - 1; j >= 0; j--) {
-        int d = c.l_dofadr + j;
+      for (int j = l_dofnum - 1; j >= 0; j--) {
+        int d = l_dofadr + j;
         V3 ax = ldv_lane(M.d_axis, d);
         int qa = M.d_qadr[d];
         V3 bax = qrot(qconj(qr), ax);
@@ -336,8 +345,8 @@ __device__ void stage1(Ctx &c) {
     Q4 q = {o[3], o[4], o[5], o[6]};
 #pragma unroll
     for (int it = 0; it < 8; it++) {
-      int a = c.lanc[it];
-      if (a >= 0) {
+      const int a = (int)(((it < 4 ? anc_lo : anc_hi) >> (8 * (it & 3))) & 0xffu);
+      if (a != 0xff) {
         const float *oa = T.lT[a];
         Q4 qa = {oa[3], oa[4], oa[5], oa[6]};
         p = V3{oa[0], oa[1], oa[2]} + qrot(qa, p);
@@ -370,20 +379,20 @@ __device__ void stage1(Ctx &c) {
   float qv = 0.f;
   if (is_dof) {
     qv = T.qvel[lane];
-    if (c.d_kind == 0) {
+    if (d_kind == 0) {
       int k = lane;  // translational root dofs are dofs 0..2
       cd = {0.f, 0.f, 0.f, k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f};
     } else {
-      const float *xo = T.xmat[c.d_link];
+      const float *xo = T.xmat[d_link];
       V3 ax;
-      if (c.d_kind == 1) {
+      if (d_kind == 1) {
         int k = lane - 3;
         ax = {xo[k], xo[3 + k], xo[6 + k]};
       } else {
         V3 b = {T.cdof[lane][0], T.cdof[lane][1], T.cdof[lane][2]};
         ax = mv(ldm(xo), b);
       }
-      V3 off = c.com - V3{T.xpos[c.d_link][0], T.xpos[c.d_link][1], T.xpos[c.d_link][2]};
+      V3 off = c.com - V3{T.xpos[d_link][0], T.xpos[d_link][1], T.xpos[d_link][2]};
       cd = mk6(ax, cross(ax, off));
     }
   }
@@ -393,7 +402,7 @@ __device__ void stage1(Ctx &c) {
   // ---- V1: velocity increment contributed by each link's own dofs
   if (is_link) {
     S6 dv = zero6();
-    for (int j = 0; j < c.l_dofnum; j++) dv = dv + T.qvel[c.l_dofadr + j] * ld6(T.cdof[c.l_dofadr + j]);
+    for (int j = 0; j < l_dofnum; j++) dv = dv + T.qvel[l_dofadr + j] * ld6(T.cdof[l_dofadr + j]);
     st6(T.la[lane], dv);
   }
   SYNC();
@@ -403,8 +412,8 @@ __device__ void stage1(Ctx &c) {
     cvel = ld6(T.la[lane]);
 #pragma unroll
     for (int it = 0; it < 8; it++) {
-      int a = c.lanc[it];
-      if (a >= 0) cvel = cvel + ld6(T.la[a]);
+      const int a = (int)(((it < 4 ? anc_lo : anc_hi) >> (8 * (it & 3))) & 0xffu);
+      if (a != 0xff) cvel = cvel + ld6(T.la[a]);
     }
     st6(T.lb[lane], cvel);
   }
@@ -412,13 +421,13 @@ __device__ void stage1(Ctx &c) {
   // ---- V3: cdof_dot = (velocity just before this dof) x cdof
   S6 cdd = zero6();
   if (is_dof) {
-    if (c.d_kind == 2) {
-      int b = c.d_link;
+    if (d_kind == 2) {
+      int b = d_link;
       int pl = M.l_parent[b];
       S6 cv = ld6(T.lb[pl]);
       for (int e = M.l_dofadr[b]; e < lane; e++) cv = cv + T.qvel[e] * ld6(T.cdof[e]);
       cdd = cross_motion(cv, cd);
-    } else if (c.d_kind == 1) {
+    } else if (d_kind == 1) {
       S6 cv = {0.f, 0.f, 0.f, T.qvel[0], T.qvel[1], T.qvel[2]};  // free joint: after the 3 translations only
       cdd = cross_motion(cv, cd);
     }
@@ -428,7 +437,7 @@ __device__ void stage1(Ctx &c) {
   // ---- A1: per-link sum of cdof_dot * qvel
   if (is_link) {
     S6 da = zero6();
-    for (int j = 0; j < c.l_dofnum; j++) da = da + T.qvel[c.l_dofadr + j] * ld6(T.cdofd[c.l_dofadr + j]);
+    for (int j = 0; j < l_dofnum; j++) da = da + T.qvel[l_dofadr + j] * ld6(T.cdofd[l_dofadr + j]);
     st6(T.la[lane], da);
   }
   SYNC();
@@ -438,65 +447,83 @@ __device__ void stage1(Ctx &c) {
     S6 cacc = ld6(T.la[lane]);
 #pragma unroll
     for (int it = 0; it < 8; it++) {
-      int a = c.lanc[it];
-      if (a >= 0) cacc = cacc + ld6(T.la[a]);
+      const int a = (int)(((it < 4 ? anc_lo : anc_hi) >> (8 * (it & 3))) & 0xffu);
+      if (a != 0xff) cacc = cacc + ld6(T.la[a]);
     }
     if (!(c.flags & FFE_NO_GRAVITY)) { cacc.l0 -= M.gx; cacc.l1 -= M.gy; cacc.l2 -= M.gz; }
     frc = mul_inert(cin, cacc) + cross_force(cvel, mul_inert(cin, cvel));
-    int kind = (c.flags & FFE_NO_FLUID) ? 0 : M.l_reckind[lane];
-    if (kind == 1) frc = frc - box_fluid(M.l_reccoef, lane, ldv_lane(M.l_recpos, lane), ldm_lane(M.l_recmat, lane), xp, xm, cvel, c.com);
-    else if (kind == 2) frc = frc - ell_fluid(M.ell + 32 * M.l_recell[lane], ldv_lane(M.l_recpos, lane), ldm_lane(M.l_recmat, lane), xp, xm, cvel, c.com);
   }
-  {
-    // bodies welded to the root link: one inertia-box record per lane, reduced across the wave
-    S6 w = zero6();
-    if (lane < M.nrootrec && !(c.flags & FFE_NO_FLUID)) {
-      V3 rp = {T.xpos[0][0], T.xpos[0][1], T.xpos[0][2]};
-      w = box_fluid(M.rr_coef, lane, ldv_lane(M.rr_pos, lane), ldm_lane(M.rr_mat, lane), rp, ldm(T.xmat[0]), ld6(T.lb[0]), c.com);
+  if (!(c.flags & FFE_NO_FLUID)) {
+    // mj_passive fluid forces, evaluated in link coordinates: (w_b, v_b) = link angular velocity / origin velocity
+    const V3 off = xp - c.com;
+    const V3 w_w = ang(cvel);
+    const V3 w_b = mtv(xm, w_w), v_b = mtv(xm, lin(cvel) + cross(w_w, off));
+    S6 wl = zero6();
+    if (is_link) {
+      const int kind = M.l_reckind[lane];
+      if (kind == 1) wl = box_fluid_local(M.l_reccoef, lane, ldv_lane(M.l_recpos, lane), ldm_lane(M.l_recmat, lane), w_b, v_b);
+      else if (kind == 2) wl = ell_fluid_local(M.ell + 32 * M.l_recell[lane], ldv_lane(M.l_recpos, lane), ldm_lane(M.l_recmat, lane), w_b, v_b);
     }
-    w = wave_sum6(w);
-    if (lane == 0) frc = frc - w;
+    // bodies welded to the root link: one inertia-box record per lane, summed across the wave in root-link axes
+    const V3 w0 = {rl_f(w_b.x, 0), rl_f(w_b.y, 0), rl_f(w_b.z, 0)}, v0 = {rl_f(v_b.x, 0), rl_f(v_b.y, 0), rl_f(v_b.z, 0)};
+    S6 wr = zero6();
+    if (lane < M.nrootrec) wr = box_fluid_local(M.rr_coef, lane, ldv_lane(M.rr_pos, lane), ldm_lane(M.rr_mat, lane), w0, v0);
+    wr = wave_sum6(wr);
+    if (lane == 0) wl = wl + wr;
+    if (is_link) {
+      const V3 f_w = mv(xm, lin(wl));
+      frc = frc - mk6(mv(xm, ang(wl)) + cross(off, f_w), f_w);
+    }
   }
   if (is_link) st6(T.lc[lane], frc);
   SYNC();
   // ---- A3: subtree sums (links are in depth-first order, so a subtree is a contiguous range) for forces and
   //          composite inertias (mj: mj_rne backward pass, mj_crb accumulation)
-  if (is_link) {
+  {
     S6 fs = frc;
     I10 cr = cin;
-    for (int k = lane + 1; k < lane + c.l_sub; k++) {
-      fs = fs + ld6(T.lc[k]);
-      cr = add10(cr, ld10(T.cinert[k]));
+    if (is_link && lane != 0) {
+      for (int k = lane + 1; k < lane + l_sub; k++) {
+        fs = fs + ld6(T.lc[k]);
+        cr = add10(cr, ld10(T.cinert[k]));
+      }
     }
-    st6(T.la[lane], fs);
-    st10(T.crb[lane], cr);
+    // the root link's subtree is the whole tree: reduce across the wave instead of an 18-step serial sum
+    const S6 ftot = wave_sum6(is_link ? frc : zero6());
+    const I10 z10 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const I10 ci = is_link ? cin : z10;
+    const I10 ctot = {wave_sum(ci.i0), wave_sum(ci.i1), wave_sum(ci.i2), wave_sum(ci.i3), wave_sum(ci.i4), wave_sum(ci.i5), wave_sum(ci.i6), wave_sum(ci.i7), wave_sum(ci.i8), wave_sum(ci.i9)};
+    if (lane == 0) { fs = ftot; cr = ctot; }
+    if (is_link) {
+      st6(T.la[lane], fs);
+      st10(T.crb[lane], cr);
+    }
   }
   SYNC();
   // ---- joint space: bias projection, joint springs and dampers; crb * cdof
   if (is_dof) {
-    float bias = dot6(cd, ld6(T.la[c.d_link]));
+    float bias = dot6(cd, ld6(T.la[d_link]));
     float f = -bias;
-    if (c.d_kind == 2) {
+    if (d_kind == 2) {
       if (!(c.flags & FFE_NO_SPRING)) f -= M.d_stiff[lane] * (T.qpos[M.d_qadr[lane]] - M.d_sref[lane]);
     }
     if (!(c.flags & FFE_NO_DAMPER)) f -= M.d_damp[lane] * qv;
     c.f_smooth_nb = f;
-    st6(T.buf[lane], mul_inert(ld10(T.crb[c.d_link]), cd));
+    st6(T.buf[lane], mul_inert(ld10(T.crb[d_link]), cd));
   }
   SYNC();
   // ---- mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs
-  if (!(c.flags & DBG_SKIP_MENTRIES))
-  for (int e = lane; e < M.nM; e += kWave) {
-    int i = M.m_row[e], j = M.m_col[e];
-    float v = dot6(ld6(T.cdof[j]), ld6(T.buf[i]));
-    if (i == j) v += M.d_arm[i];
-    T.M[e] = v;
+  if (!(c.flags & DBG_SKIP_MENTRIES)) {
+    for (int e = lane; e < M.nM; e += kWave) {
+      const int i = M.m_row[e], j = M.m_col[e];
+      float v = dot6(ld6(T.cdof[j]), ld6(T.buf[i]));
+      if (i == j) v += M.d_arm[i];
+      T.M[e] = v;
+    }
   }
   SYNC();
 }
 
-__device__ __forceinline__ int rl_i(int v, int lane_idx) { return __builtin_amdgcn_readlane(v, lane_idx); }
-__device__ __forceinline__ float rl_f(float v, int lane_idx) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx)); }
 
 // mj: mj_factorI on (M + diag(add)).  Tree-sparse L'DL in MuJoCo's row layout (row i = [M(i,i), M(i,parent), ...]);
 // rows are left unscaled and 1/D is kept per lane (c.dinv).  Pivots run leaf -> root; pivot k with n ancestors
@@ -509,13 +536,17 @@ __device__ __forceinline__ float rl_f(float v, int lane_idx) { return __int_as_f
 // (an active-set change) and leaves the Euler factor in .y untouched.
 template <bool DUAL>
 __device__ void factor(Ctx &c, float add0, float add1) {
-  const DevModel &M = *c.Mp;
+  const DevModel &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
+  const int d_madr = M.d_madr[lane], d_depth = M.d_depth[lane];
+  unsigned pr[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) pr[r] = M.pairtab[lane + r * kWave];
   if (c.flags & DBG_SKIP_FACTOR) {
-    c.dinv[0] = lane < nv ? 1.0f / (T.M[c.d_madr] + add0) : 0.f;
-    if (DUAL) c.dinv[1] = lane < nv ? 1.0f / (T.M[c.d_madr] + add1) : 0.f;
+    c.dinv[0] = lane < nv ? 1.0f / (T.M[d_madr] + add0) : 0.f;
+    if (DUAL) c.dinv[1] = lane < nv ? 1.0f / (T.M[d_madr] + add1) : 0.f;
     return;
   }
   for (int e = lane; e < M.nM; e += kWave) {
@@ -524,14 +555,14 @@ __device__ void factor(Ctx &c, float add0, float add1) {
   }
   SYNC();
   if (lane < nv) {
-    T.LD[c.d_madr].x += add0;
-    if (DUAL) T.LD[c.d_madr].y += add1;
+    T.LD[d_madr].x += add0;
+    if (DUAL) T.LD[d_madr].y += add1;
   }
   SYNC();
 #pragma unroll 1
   for (int k = nv - 1; k > 0; k--) {
-    const int n = rl_i(c.d_depth, k) - 1;
-    const int mk = rl_i(c.d_madr, k);
+    const int n = rl_i(d_depth, k) - 1;
+    const int mk = rl_i(d_madr, k);
     const int cnt = (n * (n + 1)) >> 1;
     float2 piv;
     if (DUAL) piv = T.LD[mk]; else piv.x = T.LD[mk].x;
@@ -541,7 +572,7 @@ __device__ void factor(Ctx &c, float add0, float add1) {
     for (int r = 0; r < 4; r++) {
       if (r * kWave < cnt) {  // wave-uniform
         if (lane + r * kWave < cnt) {
-          const int sidx = c.pair_s[r], tidx = c.pair_t[r];
+          const int sidx = pr[r] & 0xff, tidx = pr[r] >> 8;
           const int tgt = (int)T.colmadr[mk + sidx] + (tidx - sidx);
           if (DUAL) {
             const float2 a = T.LD[mk + sidx], b = T.LD[mk + tidx];
@@ -558,11 +589,11 @@ __device__ void factor(Ctx &c, float add0, float add1) {
     SYNC();
   }
   if (DUAL) {
-    const float2 d = T.LD[c.d_madr];
+    const float2 d = T.LD[d_madr];
     c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(d.x) : 0.f;
     c.dinv[1] = lane < nv ? __builtin_amdgcn_rcpf(d.y) : 0.f;
   } else {
-    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(T.LD[c.d_madr].x) : 0.f;
+    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(T.LD[d_madr].x) : 0.f;
   }
 }
 
@@ -570,18 +601,19 @@ __device__ void factor(Ctx &c, float add0, float add1) {
 // the factor is only read, so there is no barrier inside the two sweeps.
 template <int COMP>
 __device__ float solve(Ctx &c, float rhs) {
-  const DevModel &M = *c.Mp;
+  const DevModel &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
+  const int d_madr = M.d_madr[lane], d_depth = M.d_depth[lane], d_ndesc = M.d_ndesc[lane];
   const bool is_dof = lane < nv;
   const float dinv = c.dinv[COMP];
   const float *LDc = reinterpret_cast<const float *>(T.LD) + COMP;  // entry e of this factor sits at LDc[2 e]
   if (c.flags & DBG_SKIP_SOLVE) return is_dof ? rhs * dinv : 0.f;
   float x = is_dof ? rhs : 0.f;
-  const int my_end = lane + c.d_ndesc;         // last descendant dof of this lane
-  const int my_md = c.d_madr + c.d_depth;      // so that row-entry addresses become (my_md - depth_of_column)
-  const int dep = c.d_depth;
+  const int my_end = lane + d_ndesc;         // last descendant dof of this lane
+  const int my_md = d_madr + d_depth;      // so that row-entry addresses become (my_md - depth_of_column)
+  const int dep = d_depth;
   // x <- L^-T x : pivots from the leaves to the root; the ancestors of i (lanes j with j < i <= j + ndesc_j) fold it
   // in.  The factor entries do not depend on x, so they are fetched four pivots ahead of the dependent chain.
   int i = nv - 1;
@@ -631,19 +663,20 @@ struct StepOut {
 // Stage 2 = mj_fwdActuation, mj_fwdAcceleration, mj_fwdConstraint (joint limits), accelerometer, mj_Euler.
 // `ctrl_force` is the per-dof generalized actuator force, already assembled.
 __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long &lo_mask, unsigned long long &hi_mask, int &iters_out) {
-  const DevModel &M = *c.Mp;
+  const DevModel &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_dof = lane < M.nv;
+  const int d_kind = M.d_kind[lane];
   const float h = M.h;
   float f = is_dof ? c.f_smooth_nb + qfrc_act : 0.f;
   float qp = 0.f, qv = 0.f;
-  if (is_dof) { qv = T.qvel[lane]; if (c.d_kind == 2) qp = T.qpos[M.d_qadr[lane]]; }
+  if (is_dof) { qv = T.qvel[lane]; if (d_kind == 2) qp = T.qpos[M.d_qadr[lane]]; }
 
   // ---- mj_instantiateLimit / mj_makeImpedance / mj_referenceConstraint for this lane's hinge
   bool ex_lo = false, ex_hi = false;
   float D_lo = 0.f, D_hi = 0.f, ar_lo = 0.f, ar_hi = 0.f;
-  if (is_dof && c.d_kind == 2 && M.d_limited[lane] && !(c.flags & FFE_NO_LIMIT)) {
+  if (is_dof && d_kind == 2 && M.d_limited[lane] && !(c.flags & FFE_NO_LIMIT)) {
     float margin = M.d_margin[lane];
     float dist_lo = qp - M.d_lo[lane], dist_hi = M.d_hi[lane] - qp;
     float dmin = M.d_solimp[lane], dmax = M.d_solimp[kLanePad + lane], width = M.d_solimp[2 * kLanePad + lane],
@@ -706,7 +739,7 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
   if (is_dof) {
     float nv_ = qv + h * ae;
     T.qvel[lane] = nv_;
-    if (c.d_kind == 2) T.qpos[M.d_qadr[lane]] = qp + h * nv_;
+    if (d_kind == 2) T.qpos[M.d_qadr[lane]] = qp + h * nv_;
   }
   SYNC();
   if (lane == 0) {
@@ -729,7 +762,7 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
 
 // mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.
 __device__ float actuation(Ctx &c, const float *ctrl_lds) {
-  const DevModel &M = *c.Mp;
+  const DevModel &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   if (c.flags & FFE_NO_ACTUATION) return 0.f;
@@ -793,7 +826,7 @@ __device__ __forceinline__ ObsLayout obs_layout(int nj, int nref) {
 // ref_displacement / ref_root_quat: tasks/base.py:237-261).  Returns |ref_displacement[0]| and ref_root_quat[0].
 __device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_idx, int step_counter,
                           float &com_dist, Q4 &rq0) {
-  const DevModel &M = *c.Mp;
+  const DevModel &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nref = K.future_steps + 1;
@@ -826,20 +859,8 @@ __device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_g
 
 __device__ __forceinline__ void load_lane_consts(Ctx &c) {
   const DevModel &M = *c.Mp;
-  const int lane = c.lane;
-  c.d_link = M.d_link[lane]; c.d_kind = M.d_kind[lane]; c.d_madr = M.d_madr[lane]; c.d_depth = M.d_depth[lane]; c.d_parent = M.d_parent[lane];
-  c.l_par = M.l_parent[lane]; c.l_dofadr = M.l_dofadr[lane]; c.l_dofnum = M.l_dofnum[lane]; c.l_sub = M.l_sub[lane];
-  int a = lane < M.nlink ? c.l_par : -1;
-#pragma unroll
-  for (int it = 0; it < 8; it++) {
-    c.lanc[it] = a;
-    a = a >= 0 ? M.l_parent[a] : -1;
-  }
-  c.d_ndesc = M.d_ndesc[lane];
-#pragma unroll
-  for (int r = 0; r < 4; r++) { unsigned pr = M.pairtab[lane + r * kWave]; c.pair_s[r] = pr & 0xff; c.pair_t[r] = pr >> 8; }
   c.dinv[0] = c.dinv[1] = 0.f;
-  for (int e = lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
+  for (int e = c.lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
 }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
@@ -854,7 +875,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   if (env >= batch) return;
   const int lane = threadIdx.x;
   EnvState &S = states[env];
-  Ctx c{Mp, T, lane, K.flags};
+  Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}};
   load_lane_consts(c);
   float *obs = obs_out + (size_t)env * K.obs_dim;
   const int nsub = M.nsub;
@@ -949,11 +970,6 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   const int nst = do_reset ? 1 : nsub;
 #pragma unroll 1
   for (int s = 0; s <= nst; s++) {
-    {
-      const DevModel *ml = Mp;
-      asm volatile("" : "+s"(ml));
-      c.Mp = ml;
-    }
     if (!(c.flags & DBG_SKIP_STAGE1) || s == 0) stage1(c);
     if (lane == 0 && (do_reset || s > 0)) {
       V3 v = mtv(ldm(T.xmat[0]), V3{T.qvel[0], T.qvel[1], T.qvel[2]});
