@@ -69,11 +69,9 @@ struct alignas(16) Tile {
   };
   float lb[kMaxLink][6];
   float lc[kMaxLink][6];
-  float M[kMaxM];
   float2 LD[kMaxM];           // two factorisations side by side: .x = constraint Hessian, .y = M + h B (Euler)
-  float dinv[kLanePad];
-  float x[kLanePad];
-  float frc[kMaxAct];
+  float frc[kMaxAct];    // actuator forces
+  float ctrl[kMaxAct];   // control staging
   unsigned short colmadr[kMaxM + 8];  // for entry e = (row k, column a): start of row a in M/LD
   float sens[12];    // running sums of the buffered sensors: acc[3], gyro[3], vel[3]
   double rootpos[4];  // free-joint position in float64
@@ -512,16 +510,7 @@ __device__ void stage1(Ctx &c) {
     st6(T.buf[lane], mul_inert(ld10(T.crb[d_link]), cd));
   }
   SYNC();
-  // ---- mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs
-  if (!(c.flags & DBG_SKIP_MENTRIES)) {
-    for (int e = lane; e < M.nM; e += kWave) {
-      const int i = M.m_row[e], j = M.m_col[e];
-      float v = dot6(ld6(T.cdof[j]), ld6(T.buf[i]));
-      if (i == j) v += M.d_arm[i];
-      T.M[e] = v;
-    }
-  }
-  SYNC();
+  // M(i,j) = cdof_j . (crb_i cdof_i) is formed directly into the factor's working copy (see factor)
 }
 
 
@@ -544,13 +533,12 @@ __device__ void factor(Ctx &c, float add0, float add1) {
   unsigned pr[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) pr[r] = M.pairtab[lane + r * kWave];
-  if (c.flags & DBG_SKIP_FACTOR) {
-    c.dinv[0] = lane < nv ? 1.0f / (T.M[d_madr] + add0) : 0.f;
-    if (DUAL) c.dinv[1] = lane < nv ? 1.0f / (T.M[d_madr] + add1) : 0.f;
-    return;
-  }
+  // mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs, written straight into the working copy
+  // (cdof and crb*cdof stay in LDS for the whole substep, so a refactorisation simply forms the entries again)
   for (int e = lane; e < M.nM; e += kWave) {
-    const float m = T.M[e];
+    const int i = M.m_row[e], j = M.m_col[e];
+    float m = dot6(ld6(T.cdof[j]), ld6(T.buf[i]));
+    if (i == j) m += M.d_arm[i] + ((c.flags & DBG_SKIP_MENTRIES) ? 1.f : 0.f);
     if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
   }
   SYNC();
@@ -559,6 +547,11 @@ __device__ void factor(Ctx &c, float add0, float add1) {
     if (DUAL) T.LD[d_madr].y += add1;
   }
   SYNC();
+  if (c.flags & DBG_SKIP_FACTOR) {
+    c.dinv[0] = lane < nv ? 1.0f / T.LD[d_madr].x : 0.f;
+    if (DUAL) c.dinv[1] = lane < nv ? 1.0f / T.LD[d_madr].y : 0.f;
+    return;
+  }
 #pragma unroll 1
   for (int k = nv - 1; k > 0; k--) {
     const int n = rl_i(d_depth, k) - 1;
@@ -947,17 +940,17 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       int ai = M.a_action[lane];
       float v = ai >= 0 ? a_in[ai] : 0.f;
       if (!(v == v)) v = 0.f;
-      T.x[lane] = v;
+      T.ctrl[lane] = v;
     }
     SYNC();
     if (lane < M.nwing) {
       // action[wings] += target - qpos[wing]; the wing actuators are the ctrl slots fed by those action entries
       float tgt = K.traj[(size_t)(K.tab_off[wb_idx] + wb_step) * 6 + lane];
       float add = tgt - T.qpos[M.wing_qadr[lane]];
-      for (int u = 0; u < M.nu; u++) if (M.a_action[u] == M.wing_action[lane]) T.x[u] += add;
+      for (int u = 0; u < M.nu; u++) if (M.a_action[u] == M.wing_action[lane]) T.ctrl[u] += add;
     }
     SYNC();
-    ctrl_reg = lane < M.nu ? T.x[lane] : 0.f;
+    ctrl_reg = lane < M.nu ? T.ctrl[lane] : 0.f;
     SYNC();
     const double *rq = K.ref_qpos + ((size_t)traj_idx * K.traj_len + step_counter) * 7, *rv = K.ref_qvel + ((size_t)traj_idx * K.traj_len + step_counter) * 6;
     if (lane < 7) T.ghost[lane] = rq[lane];
