@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("FLYBODY_ENV_LIB") or os.path.join(_HERE, "csrc", "lib
 
 SYMBOLS = [
     "ffe_create_flight", "ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step",
-    "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps",
+    "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps",
     "ffe_test_quat", "ffe_last_error", "ffe_version",
 ]
 
@@ -54,6 +54,8 @@ def lib():
     L.ffe_action_bounds.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ffe_reset.argtypes = [vp, fp, fp, fp, ip, vp]
     L.ffe_step.argtypes = [vp, fp, fp, fp, fp, ip, vp]
+    L.ffe_physics_step.argtypes = [vp, fp, C.c_int, vp]
+    L.ffe_physics_step.restype = C.c_int
     L.ffe_force_next_episode.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.ffe_get_state.argtypes = [vp, dp, dp, vp]
     L.ffe_set_state.argtypes = [vp, dp, dp, vp]
@@ -63,7 +65,7 @@ def lib():
     L.ffe_last_error.restype = C.c_char_p
     L.ffe_last_error.argtypes = [vp]
     L.ffe_version.restype = C.c_char_p
-    for s in ("ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step", "ffe_force_next_episode", "ffe_get_state",
+    for s in ("ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step", "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state",
               "ffe_set_state", "ffe_get_task_state", "ffe_time_steps", "ffe_test_quat"):
         getattr(L, s).restype = C.c_int
     _lib = L

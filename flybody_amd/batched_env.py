@@ -183,6 +183,12 @@ class BatchedFlyEnv:
         self._check(self._L.ffe_set_state(self._h, qpos.data_ptr(), qvel.data_ptr(), self._stream()))
         t.cuda.current_stream(self.device).synchronize()
 
+    def physics_step(self, ctrl, nsteps: int = 1):
+        """`physics.set_control(ctrl)` then `nsteps` x `physics.step()` for every env, no task layer (BASELINE config 2).
+        `ctrl`: float32 [B, nu] cuda tensor."""
+        assert ctrl.is_cuda and ctrl.dtype == self._torch.float32 and ctrl.is_contiguous() and tuple(ctrl.shape) == (self.batch_size, self.spec.nu)
+        self._check(self._L.ffe_physics_step(self._h, ctrl.data_ptr(), int(nsteps), self._stream()))
+
     def get_task_state(self):
         t = self._torch
         ints = t.empty(self.batch_size, 8, dtype=t.int32, device=self.device)

@@ -857,10 +857,11 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
 }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
-// One launch = one dm_env step of every env.  mode: 0 = step (auto-reset envs that ended), 1 = reset all.
+// One launch = one dm_env step of every env.  mode: 0 = step (auto-reset envs that ended), 1 = reset all,
+// 2 = bare physics: `nphys` mj_steps with ctrl taken verbatim from act[B][nu] (no task, no outputs) - BASELINE config 2.
 __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(const DevModel *__restrict__ Mp, const TaskDev *__restrict__ Kp, EnvState *__restrict__ states, const float *__restrict__ act,
                                                               float *__restrict__ obs_out, float *__restrict__ reward_out,
-                                                              float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode) {
+                                                              float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode, int nphys) {
   __shared__ Tile T;
   const DevModel &M = *Mp;
   const TaskDev &K = *Kp;
@@ -871,14 +872,15 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}};
   load_lane_consts(c);
   float *obs = obs_out + (size_t)env * K.obs_dim;
-  const int nsub = M.nsub;
+  const bool phys_only = (mode == 2);
+  const int nsub = phys_only ? nphys : M.nsub;
 
   if (lane < 3) T.rootpos[lane] = S.rootpos[lane];
   if (lane < 9) T.sens[lane] = 0.f;
   unsigned long long lo_mask = S.lo_mask, hi_mask = S.hi_mask;
   int wb_step = S.wb_step, wb_idx = S.wb_freq_idx, step_counter = S.step_counter, traj_idx = S.traj_idx;
   double wb_cf = S.wb_ctrl_freq;
-  const bool do_reset = (mode == 1) || (S.needs_reset != 0);
+  const bool do_reset = !phys_only && ((mode == 1) || (S.needs_reset != 0));
   int iters = 0;
 
   // ---- prepare: either start a new episode or load the env's state and run the task pre-step
@@ -915,6 +917,11 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       T.qvel[M.wing_dof[lane]] = (float)(((double)q1 - (double)q0) / K.dt_ctrl);
     }
     lo_mask = hi_mask = 0ULL;
+    SYNC();
+  } else if (phys_only) {
+    if (lane < kMaxDof + 4) { T.qpos[lane] = S.qpos[lane]; T.qvel[lane] = S.qvel[lane]; }
+    if (lane < 13) T.ghost[lane] = lane == 3 ? 1.0 : 0.0;
+    ctrl_reg = lane < M.nu ? act[(size_t)env * M.nu + lane] : 0.f;
     SYNC();
   } else {
     if (lane < kMaxDof + 4) { T.qpos[lane] = S.qpos[lane]; T.qvel[lane] = S.qvel[lane]; }
@@ -1000,6 +1007,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   }
   SYNC();
   V3 s_acc = {T.sens[0], T.sens[1], T.sens[2]}, s_gyro = {T.sens[3], T.sens[4], T.sens[5]}, s_vel = {T.sens[6], T.sens[7], T.sens[8]};
+  if (!phys_only) {
   const float inv = (do_reset && K.pad_first_obs) ? 1.f : 1.f / (float)nsub;
   float cdist;
   Q4 rq0;
@@ -1039,6 +1047,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   }
   if (lane < 7) S.ghost[lane] = T.ghost[lane];
   if (lane == 0) S.episode = episode;
+  }  // !phys_only
   // ---- store state
   if (lane < kMaxDof + 4) { S.qpos[lane] = T.qpos[lane]; S.qvel[lane] = T.qvel[lane]; }
   if (lane == 0) {
@@ -1232,11 +1241,11 @@ int ffe_action_bounds(ffe_handle h, float *mn, float *mx) {
   return 0;
 }
 
-static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode) {
+static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys = 0) {
   if (!h) return -1;
-  if (!obs || !rew || !disc || !st || (mode == 0 && !act)) { h->err = "null device buffer"; return -1; }
+  if (mode != 2 && (!obs || !rew || !disc || !st || (mode == 0 && !act))) { h->err = "null device buffer"; return -1; }
   hipLaunchKernelGGL(flight_step_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->dm_dev, h->task_dev, h->states, act, obs, rew,
-                     disc, st, h->batch, mode);
+                     disc, st, h->batch, mode, nphys);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
   return 0;
@@ -1245,6 +1254,11 @@ static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, f
 int ffe_reset(ffe_handle h, float *obs, float *rew, float *disc, int32_t *st, void *stream) { return launch_step(h, nullptr, obs, rew, disc, st, stream, 1); }
 int ffe_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream) {
   return launch_step(h, act, obs, rew, disc, st, stream, 0);
+}
+
+int ffe_physics_step(ffe_handle h, const float *ctrl, int nsteps, void *stream) {
+  if (!h || !ctrl || nsteps <= 0) return -1;
+  return launch_step(h, ctrl, nullptr, nullptr, nullptr, nullptr, stream, 2, nsteps);
 }
 
 int ffe_force_next_episode(ffe_handle h, const int32_t *traj, const double *phase) {

@@ -85,6 +85,11 @@ int ffe_reset(ffe_handle h, float *obs_dev, float *reward_dev, float *discount_d
 int ffe_step(ffe_handle h, const float *act_dev, float *obs_dev, float *reward_dev, float *discount_dev,
              int32_t *step_type_dev, void *stream);
 
+/* physics.set_control(ctrl) + nsteps x physics.step() with no task layer (fruitfly/fruitfly.py:492 reaching MuJoCo's mj_step):
+ * advances every env's (qpos, qvel) by `nsteps` physics steps under ctrl_dev[B][nu] (clamped to ctrlrange).  BASELINE config 2
+ * ("free-flight, dynamics only"); combine with FFE_NO_LIMIT for "constraints off".  Produces no observation. */
+int ffe_physics_step(ffe_handle h, const float *ctrl_dev, int nsteps, void *stream);
+
 /* FlightImitationWBPG.set_next_trajectory_index (flight_imitation.py:87-91), plus the initial wing-beat phase
  * the reference draws from its RandomState (flight_imitation.py:137).  Host arrays [B]; traj_idx<0 keeps the
  * counter-based draw.  Applies to each env's next reset only. */

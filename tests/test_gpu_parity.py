@@ -249,3 +249,184 @@ def test_full_batch_properties(torch_mod, wb_tables, ref_traj):
         ts = env.step(a[:64].contiguous())
     assert torch.equal(env.flat_observation, outs[0][0][:64])
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config 2
+def test_config2_free_flight_dynamics_only(torch_mod, wb_tables, ref_traj):
+    """BASELINE configs[1]: free flight, constraints off, B=4096, dynamics only (no task layer): ffe_physics_step
+    against the oracle's mj_step on a 48-env sample, 40 physics steps, fresh ctrl every 4."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+    from flybody_amd.model.blob import read_blob
+    from oracle import oracle as O
+
+    torch = torch_mod
+    B = 4096
+    env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=0, physics_flags=2)  # FFE_NO_LIMIT
+    blob = read_blob(BLOB)
+    nq, nv, nu = env.spec.nq, env.spec.nv, env.spec.nu
+    rng = np.random.RandomState(5)
+    th = np.deg2rad(47.5)
+    qpos = np.tile(blob["qpos0"], (B, 1))
+    qpos[:, :3] = [0.0, 0.0, 1.0]
+    qpos[:, 3:7] = [np.cos(th / 2), 0, -np.sin(th / 2), 0]
+    wing = [int(blob["jnt_qposadr"][j]) for j in blob["wing_jnt"]]
+    qpos[:, wing] = rng.uniform(-0.8, 0.8, (B, 6))
+    qvel = np.zeros((B, nv))
+    qvel[:, 0] = 30.0
+    qvel[:, 6:] = rng.randn(B, nv - 6) * 5.0
+    env.set_state(torch.tensor(qpos), torch.tensor(qvel))
+    om = O.OracleModel(BLOB)
+    om.set_flags(O.FO_NO_LIMIT)
+    sample = list(range(0, B, B // 48))[:48]
+    datas = []
+    for i in sample:
+        d = O.OracleData(om)
+        d.qpos[:] = qpos[i]; d.qvel[:] = qvel[i]
+        datas.append(d)
+    lo, hi = blob["act_ctrlrange"][:, 0], blob["act_ctrlrange"][:, 1]
+    worst_q, worst_v = 0.0, 0.0
+    for k in range(10):
+        ctrl = (lo + (hi - lo) * rng.uniform(0, 1, (B, nu))).astype(np.float32)
+        env.physics_step(torch.tensor(ctrl, device="cuda"), 4)
+        gq, gv = [x.cpu().numpy() for x in env.get_state()]
+        for d, i in zip(datas, sample):
+            d.ctrl[:] = ctrl[i]
+            for _ in range(4):
+                d.step()
+            worst_q = max(worst_q, _scaled_err(gq[i], d.qpos))
+            worst_v = max(worst_v, np.max(np.abs(gv[i] - d.qvel)) / max(1.0, np.abs(d.qvel).max()))
+    print("config 2 open-loop 40 substeps: qpos", worst_q, "qvel (rel. to max |qvel|)", worst_v)
+    assert np.isfinite(gq).all() and np.isfinite(gv).all()
+    assert worst_q < 2e-5 and worst_v < 2e-5
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+def _mk(torch_mod, wb_tables, rq, rv, B, **kw):
+    from flybody_amd.batched_env import BatchedFlyEnv
+    from oracle import oracle as O
+
+    env = BatchedFlyEnv(wb_tables, rq, rv, batch_size=B, seed=9, **kw)
+    om = O.OracleModel(BLOB)
+    okw = {k: v for k, v in kw.items() if k in ("future_steps", "terminal_com_dist")}
+    if "time_limit" in kw:
+        okw["time_limit_steps"] = int(round(kw["time_limit"] / wb_tables.dt_ctrl))
+    oenvs = [O.OracleFlightEnv(om, wb_tables, rq, rv, ghost_accel_z=env.ghost_accel_z, seed=9, env_id=i, **okw) for i in range(B)]
+    return env, oenvs
+
+
+def test_nan_actions_are_scrubbed(torch_mod, wb_tables, ref_traj):
+    torch = torch_mod
+    outs = []
+    for poison in (False, True):
+        env, _ = _mk(torch_mod, wb_tables, *ref_traj, B=8)
+        env.set_next_trajectory_index(np.arange(8) % 8, np.full(8, 0.25))
+        env.reset()
+        a = torch.zeros(8, 12, device="cuda")
+        if poison:
+            a[:, 4] = float("nan"); a[3, 11] = float("nan")
+        ts = env.step(a)
+        outs.append((env.flat_observation.clone(), ts.reward.clone()))
+        assert not torch.isnan(a[:, :4]).any()  # the caller's buffer is not written
+        env.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fatal_terminations_match_oracle(torch_mod, wb_tables, ref_traj):
+    """height < 0.2 cm and |ref_displacement| > terminal_com_dist end the episode with discount 0."""
+    torch = torch_mod
+    env, oenvs = _mk(torch_mod, wb_tables, *ref_traj, B=4, terminal_com_dist=0.5)
+    traj, phase = np.zeros(4, int), np.full(4, 0.1)
+    env.set_next_trajectory_index(traj, phase)
+    env.reset()
+    for i, e in enumerate(oenvs):
+        e.force_next(0, 0.1); e.reset()
+    q, v = [x.cpu().numpy() for x in env.get_state()]
+    q[0, 2] = 0.15            # below the terminal height
+    q[1, 0] += 0.8            # farther than terminal_com_dist from the ghost
+    env.set_state(torch.tensor(q), torch.tensor(v))
+    for i, e in enumerate(oenvs):
+        e.data.qpos[:] = q[i]; e.data.qvel[:] = v[i]
+    a = np.zeros((4, 12), np.float32)
+    ts = env.step(torch.tensor(a, device="cuda"))
+    st, disc, rew = ts.step_type.cpu().numpy(), ts.discount.cpu().numpy(), ts.reward.cpu().numpy()
+    for i, e in enumerate(oenvs):
+        ost, orr, od, _ = e.step(a[i].astype(np.float64))
+        assert (ost, od) == (st[i], disc[i]) and abs(orr - rew[i]) < 1e-5
+    assert list(st) == [2, 2, 1, 1] and list(disc) == [0, 0, 1, 1]
+    env.close()
+
+
+def test_trajectory_end_is_a_good_termination(torch_mod, wb_tables, ref_traj):
+    """step == len(traj) - (future_steps + 1): LAST with discount 1 (flight_imitation.py:107-108,211-220)."""
+    torch = torch_mod
+    rq, rv = ref_traj[0][:, :20].copy(), ref_traj[1][:, :20].copy()
+    env, oenvs = _mk(torch_mod, wb_tables, rq, rv, B=4, terminal_com_dist=1e9)
+    env.set_next_trajectory_index(np.arange(4), np.full(4, 0.3))
+    env.reset()
+    for i, e in enumerate(oenvs):
+        e.force_next(i, 0.3); e.reset()
+    a = np.zeros((4, 12), np.float32)
+    seen = []
+    for k in range(16):
+        ts = env.step(torch.tensor(a, device="cuda"))
+        st, disc = ts.step_type.cpu().numpy(), ts.discount.cpu().numpy()
+        for i, e in enumerate(oenvs):
+            ost, orr, od, _ = e.step(a[i].astype(np.float64))
+            assert (ost, od) == (st[i], disc[i]), (k, i)
+        seen.append((int(st[0]), float(disc[0])))
+    assert seen[13] == (2, 1.0) and seen[14][0] == 0 and all(s == (1, 1.0) for s in seen[:13])
+    env.close()
+
+
+def test_time_limit_termination(torch_mod, wb_tables, ref_traj):
+    torch = torch_mod
+    env, oenvs = _mk(torch_mod, wb_tables, *ref_traj, B=2, terminal_com_dist=1e9, time_limit=10 * 2e-4 + 14 * 2e-4)
+    # time_limit_steps = 24 > traj_timesteps = 24 - 6 = 18: the trajectory-end rule fires first at 18, as in the reference
+    env.reset()
+    for e in oenvs:
+        e.reset()
+    a = np.zeros((2, 12), np.float32)
+    lasts = []
+    for k in range(20):
+        ts = env.step(torch.tensor(a, device="cuda"))
+        st = ts.step_type.cpu().numpy()
+        for i, e in enumerate(oenvs):
+            ost, _, od, _ = e.step(a[i].astype(np.float64))
+            assert ost == st[i] and od == ts.discount.cpu().numpy()[i]
+        if st[0] == 2:
+            lasts.append(k)
+    assert lasts == [17]
+    env.close()
+
+
+def test_first_observation_padding_flag(torch_mod, wb_tables, ref_traj):
+    """dm_control zero-pads the 4-sample sensor buffers at reset (first means = value / 4); pad_first_obs=True repeats
+    the first value instead."""
+    torch = torch_mod
+    obs = {}
+    for pad in (False, True):
+        env, oenvs = _mk(torch_mod, wb_tables, *ref_traj, B=2, pad_first_obs=pad)
+        env.set_next_trajectory_index([1, 2], [0.2, 0.6])
+        env.reset()
+        o = env.flat_observation.cpu().numpy().astype(np.float64)
+        for i, e in enumerate(oenvs):
+            e.set_pad_first_obs(pad); e.force_next(i + 1, [0.2, 0.6][i])
+            _, _, _, oo = e.reset()
+            assert _obs_err(o[i], oo) < TOL_OBS_1STEP
+        obs[pad] = o
+        env.close()
+    for name in ("accelerometer", "gyro", "velocimeter"):
+        lo, hi = OBS_GROUPS[name]
+        np.testing.assert_allclose(4 * obs[False][:, lo:hi], obs[True][:, lo:hi], rtol=1e-6, atol=1e-6)
+
+
+def test_single_env_and_full_range_actions(torch_mod, wb_tables, ref_traj):
+    """B = 1 works, and full-range random actions (wing joints driven hard into their limits) stay within tolerance
+    teacher-forced."""
+    env, oenvs = _mk(torch_mod, wb_tables, *ref_traj, B=1)
+    errs, stats = _rollout(env, oenvs, torch_mod, 150, teacher=True, seed=21, act_scale=1.0)
+    print("B=1 full-range actions, teacher-forced:", {k: float(v.max()) for k, v in errs.items()}, stats)
+    assert stats["compared"] >= 140
+    assert errs["obs"].max() < TOL_OBS_1STEP and errs["reward"].max() < TOL_REWARD_1STEP
+    env.close()
