@@ -649,6 +649,57 @@ __device__ float solve(Ctx &c, float rhs) {
   return x;
 }
 
+// Both resident factors applied to the same right-hand side in one pair of sweeps (float2 factor entries, shared
+// predicates and index arithmetic): used when no joint limit is instantiated, where qacc = M^-1 f and the Euler
+// acceleration (M + h B)^-1 f differ only in the factor.
+__device__ float2 solve_both(Ctx &c, float rhs) {
+  const DevModel &M = model(c);
+  Tile &T = c.T;
+  const int lane = c.lane;
+  const int nv = M.nv;
+  const bool is_dof = lane < nv;
+  const int d_madr = M.d_madr[lane], d_depth = M.d_depth[lane], d_ndesc = M.d_ndesc[lane];
+  const float di0 = c.dinv[0], di1 = c.dinv[1];
+  if (c.flags & DBG_SKIP_SOLVE) return is_dof ? make_float2(rhs * di0, rhs * di1) : make_float2(0.f, 0.f);
+  float x0 = is_dof ? rhs : 0.f, x1 = x0;
+  const int my_end = lane + d_ndesc, my_md = d_madr + d_depth, dep = d_depth;
+  const float2 z2 = make_float2(0.f, 0.f);
+  int i = nv - 1;
+#pragma unroll 1
+  for (; i >= 2; i -= 2) {
+    const bool p0 = lane < i && i <= my_end, p1 = lane < i - 1 && i - 1 <= my_end;
+    const float2 l0 = p0 ? T.LD[rl_i(my_md, i) - dep] : z2, l1 = p1 ? T.LD[rl_i(my_md, i - 1) - dep] : z2;
+    x0 -= l0.x * (rl_f(x0, i) * rl_f(di0, i));
+    x1 -= l0.y * (rl_f(x1, i) * rl_f(di1, i));
+    x0 -= l1.x * (rl_f(x0, i - 1) * rl_f(di0, i - 1));
+    x1 -= l1.y * (rl_f(x1, i - 1) * rl_f(di1, i - 1));
+  }
+#pragma unroll 1
+  for (; i > 0; i--) {
+    const float2 l0 = (lane < i && i <= my_end) ? T.LD[rl_i(my_md, i) - dep] : z2;
+    x0 -= l0.x * (rl_f(x0, i) * rl_f(di0, i));
+    x1 -= l0.y * (rl_f(x1, i) * rl_f(di1, i));
+  }
+  x0 *= di0; x1 *= di1;
+  int j = 0;
+#pragma unroll 1
+  for (; j + 2 <= nv - 1; j += 2) {
+    const bool p0 = lane > j && lane <= rl_i(my_end, j), p1 = lane > j + 1 && lane <= rl_i(my_end, j + 1);
+    const float2 l0 = p0 ? T.LD[my_md - rl_i(dep, j)] : z2, l1 = p1 ? T.LD[my_md - rl_i(dep, j + 1)] : z2;
+    x0 -= l0.x * di0 * rl_f(x0, j);
+    x1 -= l0.y * di1 * rl_f(x1, j);
+    x0 -= l1.x * di0 * rl_f(x0, j + 1);
+    x1 -= l1.y * di1 * rl_f(x1, j + 1);
+  }
+#pragma unroll 1
+  for (; j < nv - 1; j++) {
+    const float2 l0 = (lane > j && lane <= rl_i(my_end, j)) ? T.LD[my_md - rl_i(dep, j)] : z2;
+    x0 -= l0.x * di0 * rl_f(x0, j);
+    x1 -= l0.y * di1 * rl_f(x1, j);
+  }
+  return make_float2(x0, x1);
+}
+
 struct StepOut {
   V3 acc_sample;  // accelerometer reading of this substep (valid on every lane)
 };
@@ -698,23 +749,30 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
   int iters = 0;
   const bool want_euler = integrate && !(c.flags & FFE_NO_DAMPER);
   const float hB = (is_dof && want_euler) ? h * M.d_damp[lane] : 0.f;
+  if (ex_any == 0ULL) {
+    // no limit instantiated: one dual factorisation, one dual solve
+    factor<true>(c, 0.f, hB);
+    if (want_euler) { const float2 r = solve_both(c, f); a = r.x; ae = r.y; }
+    else { a = solve<0>(c, f); ae = a; }
+  } else {
 #pragma unroll 1
-  for (int it = 0; it < 8; it++) {
-    const float add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
-    const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
-    if (it == 0) factor<true>(c, add, hB);   // constraint Hessian and Euler matrix in one sweep
-    else factor<false>(c, add, 0.f);          // active set changed: refactor the Hessian only
-    a = solve<0>(c, rhs);
-    iters++;
-    const bool n_lo = ex_lo && (a - ar_lo < 0.f);
-    const bool n_hi = ex_hi && (-a - ar_hi < 0.f);
-    const bool changed = (n_lo != act_lo) || (n_hi != act_hi);
-    act_lo = n_lo; act_hi = n_hi;
-    if (ex_any == 0ULL || __ballot(changed) == 0ULL) break;
+    for (int it = 0; it < 8; it++) {
+      const float add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
+      const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
+      if (it == 0) factor<true>(c, add, hB);   // constraint Hessian and Euler matrix in one sweep
+      else factor<false>(c, add, 0.f);          // active set changed: refactor the Hessian only
+      a = solve<0>(c, rhs);
+      iters++;
+      const bool n_lo = ex_lo && (a - ar_lo < 0.f);
+      const bool n_hi = ex_hi && (-a - ar_hi < 0.f);
+      const bool changed = (n_lo != act_lo) || (n_hi != act_hi);
+      act_lo = n_lo; act_hi = n_hi;
+      if (__ballot(changed) == 0ULL) break;
+    }
+    if (act_lo) fc += D_lo * (ar_lo - a);
+    if (act_hi) fc -= D_hi * (ar_hi + a);
+    ae = want_euler ? solve<1>(c, f + fc) : a;
   }
-  if (act_lo) fc += D_lo * (ar_lo - a);
-  if (act_hi) fc -= D_hi * (ar_hi + a);
-  ae = want_euler ? solve<1>(c, f + fc) : a;
   lo_mask = __ballot(act_lo);
   hi_mask = __ballot(act_hi);
   iters_out = ex_any ? iters : 0;
