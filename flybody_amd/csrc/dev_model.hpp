@@ -13,6 +13,15 @@
 #include <string>
 #include <vector>
 
+// Pointers stored inside structs that live in device memory lose their address space when the compiler cannot trace
+// them back to a kernel argument, and are then dereferenced with FLAT loads (slower, and they tie the LDS and vector
+// memory wait counters together).  Declaring them global on the device side makes every table read a global_load.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FFE_GLOBAL __attribute__((address_space(1)))
+#else
+#define FFE_GLOBAL
+#endif
+
 namespace ffe {
 
 constexpr int kWave = 64;
@@ -20,6 +29,7 @@ constexpr int kMaxLink = 20;  // LDS capacity (flight model: 19)
 constexpr int kMaxDof = 44;   // LDS capacity (flight model: 42)
 constexpr int kMaxM = 424;    // LDS capacity (flight model: 421)
 constexpr int kMaxAct = 16;
+constexpr int kMaxWrap = 8;   // transmission terms per actuator (joint: 1, fixed tendon: its joints)
 constexpr int kMaxObsJ = 32;
 constexpr int kMaxFuture = 8;
 constexpr int kLanePad = 64;  // every lane-major table is padded to a full wave
@@ -76,29 +86,30 @@ struct DevModel {
   int nlink, nv, nq, nu, nM, ntri, nrootrec, nobsj, nwing, naction, maxdepth, nsub;
   float h, gx, gy, gz, total_mass;
   // per dof
-  const int *d_parent, *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id, *d_ndesc;  // d_act_id: [2][64]
-  const unsigned int *pairtab;  // [256] elimination pairs (s | t << 8), sorted by t then s
-  const float *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
+  const int FFE_GLOBAL *d_parent, *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id, *d_ndesc;  // d_act_id: [2][64]
+  const unsigned int FFE_GLOBAL *pairtab;  // [256] elimination pairs (s | t << 8), sorted by t then s
+  const float FFE_GLOBAL *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
       *d_act_coef;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
   // per link
-  const int *l_parent, *l_dofadr, *l_dofnum, *l_sub, *l_reckind, *l_recell;
-  const unsigned int *l_anc;  // [2][64] ancestor links packed as bytes, nearest first, 0xff = none
-  const float *l_pos, *l_quat, *l_ipos, *l_imat, *l_inertia, *l_mass, *l_recpos, *l_recmat, *l_reccoef;
+  const int FFE_GLOBAL *l_parent, *l_dofadr, *l_dofnum, *l_sub, *l_reckind, *l_recell;
+  const unsigned int FFE_GLOBAL *l_anc;  // [2][64] ancestor links packed as bytes, nearest first, 0xff = none
+  const float FFE_GLOBAL *l_pos, *l_quat, *l_ipos, *l_imat, *l_inertia, *l_mass, *l_recpos, *l_recmat, *l_reccoef;
   // fluid records on the root link, one per lane
-  const float *rr_pos, *rr_mat, *rr_coef;
+  const float FFE_GLOBAL *rr_pos, *rr_mat, *rr_coef;
   // ellipsoid parameter blocks [nell][32]
-  const float *ell;
+  const float FFE_GLOBAL *ell;
   // sparse-M index tables
-  const unsigned char *m_row, *m_col;
-  const unsigned int *tri;
-  const int *tri_off;  // [nv+1]
+  const unsigned char FFE_GLOBAL *m_row, *m_col;
+  const unsigned int FFE_GLOBAL *tri;
+  const int FFE_GLOBAL *tri_off;  // [nv+1]
   // actuators
-  const int *a_trn, *a_dof, *a_qadr, *a_cl, *a_fl, *a_action, *a_wrap_off, *w_qadr, *w_dof;
-  const float *a_gain, *a_b0, *a_b1, *a_b2, *a_clo, *a_chi, *a_flo, *a_fhi, *w_coef;
+  const int FFE_GLOBAL *a_trn, *a_dof, *a_qadr, *a_cl, *a_fl, *a_action, *a_wrap_off, *w_qadr, *w_dof, *t_qadr, *t_dof;
+  const float FFE_GLOBAL *t_coef;
+  const float FFE_GLOBAL *a_gain, *a_b0, *a_b1, *a_b2, *a_clo, *a_chi, *a_flo, *a_fhi, *w_coef;
   // task bookkeeping
-  const int *wing_dof, *wing_qadr, *wing_action, *obsj_qadr, *obsj_dof;
+  const int FFE_GLOBAL *wing_dof, *wing_qadr, *wing_action, *obsj_qadr, *obsj_dof;
   int user_action;
-  const float *qpos0;  // [nq]
+  const float FFE_GLOBAL *qpos0;  // [nq]
 };
 
 struct BoxCoef { float c[8]; };  // visc_ang, visc_lin, quad_lin[3], quad_ang[3]
@@ -152,7 +163,7 @@ struct HostModel {
     dst = view;
     auto fix = [&](auto &p) {
       using P = std::remove_reference_t<decltype(p)>;
-      p = reinterpret_cast<P>(base + reinterpret_cast<size_t>(p));
+      p = (P)((size_t)base + (size_t)p);  // C-style: the member may carry a device address-space qualifier
     };
     fix(dst.d_parent); fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
     fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
@@ -164,7 +175,7 @@ struct HostModel {
     fix(dst.rr_pos); fix(dst.rr_mat); fix(dst.rr_coef); fix(dst.ell);
     fix(dst.m_row); fix(dst.m_col); fix(dst.tri); fix(dst.tri_off);
     fix(dst.a_trn); fix(dst.a_dof); fix(dst.a_qadr); fix(dst.a_cl); fix(dst.a_fl); fix(dst.a_action);
-    fix(dst.a_wrap_off); fix(dst.w_qadr); fix(dst.w_dof);
+    fix(dst.a_wrap_off); fix(dst.w_qadr); fix(dst.w_dof); fix(dst.t_qadr); fix(dst.t_dof); fix(dst.t_coef);
     fix(dst.a_gain); fix(dst.a_b0); fix(dst.a_b1); fix(dst.a_b2); fix(dst.a_clo); fix(dst.a_chi); fix(dst.a_flo);
     fix(dst.a_fhi); fix(dst.w_coef);
     fix(dst.wing_dof); fix(dst.wing_qadr); fix(dst.wing_action); fix(dst.obsj_qadr); fix(dst.obsj_dof);
@@ -172,7 +183,8 @@ struct HostModel {
   }
 };
 
-#define FFE_OFF(T, off) reinterpret_cast<T>(static_cast<size_t>(off))
+template <typename P>
+inline void set_off(P &p, size_t off) { p = (P)off; }  // arena offset now, device address after fixup()
 
 inline HostModel build_host_model(const Blob &b) {
   HostModel H;
@@ -417,6 +429,21 @@ inline HostModel build_host_model(const Blob &b) {
     } else throw std::runtime_error("body (adhesion) transmissions are not supported yet");
   }
   for (int u = nu; u <= kMaxAct; u++) a_wrap_off[u] = static_cast<int>(w_qadr.size());
+  // transposed, zero-padded transmission table [term][actuator]: every actuator - joint or tendon driven - is a sum of
+  // up to kMaxWrap (coef, dof) terms, so the kernel evaluates length and velocity without a data-dependent loop
+  std::vector<int> t_qadr(kMaxWrap * kMaxAct, 0), t_dof(kMaxWrap * kMaxAct, 0);
+  std::vector<float> t_coef(kMaxWrap * kMaxAct, 0.f);
+  for (int u = 0; u < nu; u++) {
+    if (a_trn[u] == 0) { t_qadr[u] = a_qadr[u]; t_dof[u] = a_dof[u]; t_coef[u] = 1.f; }
+    else {
+      int n = a_wrap_off[u + 1] - a_wrap_off[u];
+      if (n > kMaxWrap) throw std::runtime_error("tendon with too many joints");
+      for (int w = 0; w < n; w++) {
+        t_qadr[w * kMaxAct + u] = w_qadr[a_wrap_off[u] + w]; t_dof[w * kMaxAct + u] = w_dof[a_wrap_off[u] + w];
+        t_coef[w * kMaxAct + u] = w_coef[a_wrap_off[u] + w];
+      }
+    }
+  }
   if (w_qadr.empty()) { w_qadr.push_back(0); w_dof.push_back(0); w_coef.push_back(0.f); }
 
   // ---- task bookkeeping ----------------------------------------------------------------------------
@@ -437,45 +464,46 @@ inline HostModel build_host_model(const Blob &b) {
   if (site.f(4) != 1.0) throw std::runtime_error("sensor site must share the root body orientation");
 
   // ---- pack ------------------------------------------------------------------------------------------
-  V.d_parent = FFE_OFF(const int *, A.put(d_parent)); V.d_link = FFE_OFF(const int *, A.put(d_link));
-  V.d_madr = FFE_OFF(const int *, A.put(d_madr)); V.d_depth = FFE_OFF(const int *, A.put(d_depth));
-  V.d_kind = FFE_OFF(const int *, A.put(d_kind)); V.d_qadr = FFE_OFF(const int *, A.put(d_qadr));
-  V.d_limited = FFE_OFF(const int *, A.put(d_limited)); V.d_act_id = FFE_OFF(const int *, A.put(d_act_id));
-  V.d_ndesc = FFE_OFF(const int *, A.put(d_ndesc)); V.pairtab = FFE_OFF(const unsigned int *, A.put(pairtab));
-  V.d_axis = FFE_OFF(const float *, A.put(d_axis)); V.d_arm = FFE_OFF(const float *, A.put(d_arm));
-  V.d_damp = FFE_OFF(const float *, A.put(d_damp)); V.d_stiff = FFE_OFF(const float *, A.put(d_stiff));
-  V.d_sref = FFE_OFF(const float *, A.put(d_sref)); V.d_lo = FFE_OFF(const float *, A.put(d_lo));
-  V.d_hi = FFE_OFF(const float *, A.put(d_hi)); V.d_margin = FFE_OFF(const float *, A.put(d_margin));
-  V.d_invw = FFE_OFF(const float *, A.put(d_invw)); V.d_K = FFE_OFF(const float *, A.put(d_K));
-  V.d_B = FFE_OFF(const float *, A.put(d_B)); V.d_solimp = FFE_OFF(const float *, A.put(d_solimp));
-  V.d_act_coef = FFE_OFF(const float *, A.put(d_act_coef));
-  V.l_anc = FFE_OFF(const unsigned int *, A.put(l_anc));
-  V.l_parent = FFE_OFF(const int *, A.put(l_parent)); V.l_dofadr = FFE_OFF(const int *, A.put(l_dofadr));
-  V.l_dofnum = FFE_OFF(const int *, A.put(l_dofnum)); V.l_sub = FFE_OFF(const int *, A.put(l_sub));
-  V.l_reckind = FFE_OFF(const int *, A.put(l_reckind)); V.l_recell = FFE_OFF(const int *, A.put(l_recell));
-  V.l_pos = FFE_OFF(const float *, A.put(l_pos)); V.l_quat = FFE_OFF(const float *, A.put(l_quat));
-  V.l_ipos = FFE_OFF(const float *, A.put(l_ipos)); V.l_imat = FFE_OFF(const float *, A.put(l_imat));
-  V.l_inertia = FFE_OFF(const float *, A.put(l_inertia)); V.l_mass = FFE_OFF(const float *, A.put(l_mass));
-  V.l_recpos = FFE_OFF(const float *, A.put(l_recpos)); V.l_recmat = FFE_OFF(const float *, A.put(l_recmat));
-  V.l_reccoef = FFE_OFF(const float *, A.put(l_reccoef));
-  V.rr_pos = FFE_OFF(const float *, A.put(rr_pos)); V.rr_mat = FFE_OFF(const float *, A.put(rr_mat));
-  V.rr_coef = FFE_OFF(const float *, A.put(rr_coef)); V.ell = FFE_OFF(const float *, A.put(ell));
-  V.m_row = FFE_OFF(const unsigned char *, A.put(m_row)); V.m_col = FFE_OFF(const unsigned char *, A.put(m_col));
-  V.tri = FFE_OFF(const unsigned int *, A.put(tri)); V.tri_off = FFE_OFF(const int *, A.put(tri_off));
-  V.a_trn = FFE_OFF(const int *, A.put(a_trn)); V.a_dof = FFE_OFF(const int *, A.put(a_dof));
-  V.a_qadr = FFE_OFF(const int *, A.put(a_qadr)); V.a_cl = FFE_OFF(const int *, A.put(a_cl));
-  V.a_fl = FFE_OFF(const int *, A.put(a_fl)); V.a_action = FFE_OFF(const int *, A.put(a_action));
-  V.a_wrap_off = FFE_OFF(const int *, A.put(a_wrap_off)); V.w_qadr = FFE_OFF(const int *, A.put(w_qadr));
-  V.w_dof = FFE_OFF(const int *, A.put(w_dof));
-  V.a_gain = FFE_OFF(const float *, A.put(a_gain)); V.a_b0 = FFE_OFF(const float *, A.put(a_b0));
-  V.a_b1 = FFE_OFF(const float *, A.put(a_b1)); V.a_b2 = FFE_OFF(const float *, A.put(a_b2));
-  V.a_clo = FFE_OFF(const float *, A.put(a_clo)); V.a_chi = FFE_OFF(const float *, A.put(a_chi));
-  V.a_flo = FFE_OFF(const float *, A.put(a_flo)); V.a_fhi = FFE_OFF(const float *, A.put(a_fhi));
-  V.w_coef = FFE_OFF(const float *, A.put(w_coef));
-  V.wing_dof = FFE_OFF(const int *, A.put(wing_dof)); V.wing_qadr = FFE_OFF(const int *, A.put(wing_qadr));
-  V.wing_action = FFE_OFF(const int *, A.put(wing_action));
-  V.obsj_qadr = FFE_OFF(const int *, A.put(obsj_qadr)); V.obsj_dof = FFE_OFF(const int *, A.put(obsj_dof));
-  V.qpos0 = FFE_OFF(const float *, A.put(qpos0));
+  set_off(V.d_parent, A.put(d_parent)); set_off(V.d_link, A.put(d_link));
+  set_off(V.d_madr, A.put(d_madr)); set_off(V.d_depth, A.put(d_depth));
+  set_off(V.d_kind, A.put(d_kind)); set_off(V.d_qadr, A.put(d_qadr));
+  set_off(V.d_limited, A.put(d_limited)); set_off(V.d_act_id, A.put(d_act_id));
+  set_off(V.d_ndesc, A.put(d_ndesc)); set_off(V.pairtab, A.put(pairtab));
+  set_off(V.d_axis, A.put(d_axis)); set_off(V.d_arm, A.put(d_arm));
+  set_off(V.d_damp, A.put(d_damp)); set_off(V.d_stiff, A.put(d_stiff));
+  set_off(V.d_sref, A.put(d_sref)); set_off(V.d_lo, A.put(d_lo));
+  set_off(V.d_hi, A.put(d_hi)); set_off(V.d_margin, A.put(d_margin));
+  set_off(V.d_invw, A.put(d_invw)); set_off(V.d_K, A.put(d_K));
+  set_off(V.d_B, A.put(d_B)); set_off(V.d_solimp, A.put(d_solimp));
+  set_off(V.d_act_coef, A.put(d_act_coef));
+  set_off(V.l_anc, A.put(l_anc));
+  set_off(V.l_parent, A.put(l_parent)); set_off(V.l_dofadr, A.put(l_dofadr));
+  set_off(V.l_dofnum, A.put(l_dofnum)); set_off(V.l_sub, A.put(l_sub));
+  set_off(V.l_reckind, A.put(l_reckind)); set_off(V.l_recell, A.put(l_recell));
+  set_off(V.l_pos, A.put(l_pos)); set_off(V.l_quat, A.put(l_quat));
+  set_off(V.l_ipos, A.put(l_ipos)); set_off(V.l_imat, A.put(l_imat));
+  set_off(V.l_inertia, A.put(l_inertia)); set_off(V.l_mass, A.put(l_mass));
+  set_off(V.l_recpos, A.put(l_recpos)); set_off(V.l_recmat, A.put(l_recmat));
+  set_off(V.l_reccoef, A.put(l_reccoef));
+  set_off(V.rr_pos, A.put(rr_pos)); set_off(V.rr_mat, A.put(rr_mat));
+  set_off(V.rr_coef, A.put(rr_coef)); set_off(V.ell, A.put(ell));
+  set_off(V.m_row, A.put(m_row)); set_off(V.m_col, A.put(m_col));
+  set_off(V.tri, A.put(tri)); set_off(V.tri_off, A.put(tri_off));
+  set_off(V.a_trn, A.put(a_trn)); set_off(V.a_dof, A.put(a_dof));
+  set_off(V.a_qadr, A.put(a_qadr)); set_off(V.a_cl, A.put(a_cl));
+  set_off(V.a_fl, A.put(a_fl)); set_off(V.a_action, A.put(a_action));
+  set_off(V.a_wrap_off, A.put(a_wrap_off)); set_off(V.w_qadr, A.put(w_qadr));
+  set_off(V.w_dof, A.put(w_dof));
+  set_off(V.t_qadr, A.put(t_qadr)); set_off(V.t_dof, A.put(t_dof)); set_off(V.t_coef, A.put(t_coef));
+  set_off(V.a_gain, A.put(a_gain)); set_off(V.a_b0, A.put(a_b0));
+  set_off(V.a_b1, A.put(a_b1)); set_off(V.a_b2, A.put(a_b2));
+  set_off(V.a_clo, A.put(a_clo)); set_off(V.a_chi, A.put(a_chi));
+  set_off(V.a_flo, A.put(a_flo)); set_off(V.a_fhi, A.put(a_fhi));
+  set_off(V.w_coef, A.put(w_coef));
+  set_off(V.wing_dof, A.put(wing_dof)); set_off(V.wing_qadr, A.put(wing_qadr));
+  set_off(V.wing_action, A.put(wing_action));
+  set_off(V.obsj_qadr, A.put(obsj_qadr)); set_off(V.obsj_dof, A.put(obsj_dof));
+  set_off(V.qpos0, A.put(qpos0));
   H.arena = A.bytes();
   return H;
 }

@@ -44,9 +44,9 @@ struct alignas(64) EnvState {
 struct TaskDev {
   int nfreq, ntraj, traj_len, future_steps, time_limit_steps, pad_first_obs, flags, obs_dim;
   double base_freq, rel_range, rate, dt_ctrl, terminal_com_dist, ghost_accel_z;
-  const double *beat_freqs, *phase, *phase_frac, *ref_qpos, *ref_qvel;
-  const float *traj;
-  const int *tab_off;
+  const double FFE_GLOBAL *beat_freqs, *phase, *phase_frac, *ref_qpos, *ref_qvel;
+  const float FFE_GLOBAL *traj;
+  const int FFE_GLOBAL *tab_off;
   unsigned long long seed, env_id_base;
 };
 
@@ -138,11 +138,11 @@ __device__ __forceinline__ S6 cross_force(S6 vel, S6 f) { return mk6(cross(ang(v
 __device__ __forceinline__ S6 ld6(const float *p) { return {p[0], p[1], p[2], p[3], p[4], p[5]}; }
 __device__ __forceinline__ void st6(float *p, S6 s) { p[0] = s.a0; p[1] = s.a1; p[2] = s.a2; p[3] = s.l0; p[4] = s.l1; p[5] = s.l2; }
 __device__ __forceinline__ M3 ldm(const float *p) { return {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]}; }
-__device__ __forceinline__ M3 ldm_lane(const float *tab, int lane) {
+__device__ __forceinline__ M3 ldm_lane(const float FFE_GLOBAL *tab, int lane) {
   return {tab[0 * kLanePad + lane], tab[1 * kLanePad + lane], tab[2 * kLanePad + lane], tab[3 * kLanePad + lane], tab[4 * kLanePad + lane],
           tab[5 * kLanePad + lane], tab[6 * kLanePad + lane], tab[7 * kLanePad + lane], tab[8 * kLanePad + lane]};
 }
-__device__ __forceinline__ V3 ldv_lane(const float *tab, int lane) { return {tab[lane], tab[kLanePad + lane], tab[2 * kLanePad + lane]}; }
+__device__ __forceinline__ V3 ldv_lane(const float FFE_GLOBAL *tab, int lane) { return {tab[lane], tab[kLanePad + lane], tab[2 * kLanePad + lane]}; }
 
 struct I10 { float i0, i1, i2, i3, i4, i5, i6, i7, i8, i9; };
 __device__ __forceinline__ I10 ld10(const float *p) { return {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9]}; }
@@ -202,7 +202,7 @@ __device__ __forceinline__ float quat_dist_short_arc(Q4 a, Q4 b) {
 // `rmat`, both in the coordinates of the link that carries it.  (w_b, v_b) = the link's angular velocity and the linear
 // velocity of the link origin, in link axes.  Returns (torque about the link origin, force) in link axes, so the
 // bodies welded to one link can be summed before a single rotation to the world.
-__device__ __forceinline__ S6 box_fluid_local(const float *coef, int lane, V3 rpos, const M3 &rmat, V3 w_b, V3 v_b) {
+__device__ __forceinline__ S6 box_fluid_local(const float FFE_GLOBAL *coef, int lane, V3 rpos, const M3 &rmat, V3 w_b, V3 v_b) {
   V3 lw = mtv(rmat, w_b), lv = mtv(rmat, v_b + cross(w_b, rpos));
   float c0 = coef[0 * kLanePad + lane], c1 = coef[1 * kLanePad + lane];
   V3 lt = {-c0 * lw.x - coef[5 * kLanePad + lane] * fabsf(lw.x) * lw.x, -c0 * lw.y - coef[6 * kLanePad + lane] * fabsf(lw.y) * lw.y,
@@ -213,7 +213,7 @@ __device__ __forceinline__ S6 box_fluid_local(const float *coef, int lane, V3 rp
   return mk6(mv(rmat, lt) + cross(rpos, f), f);
 }
 // mj: ellipsoid fluid model (mj_ellipsoidFluidModel + mj_addedMassForces + mj_viscousForces), same conventions
-__device__ __forceinline__ S6 ell_fluid_local(const float *e, V3 rpos, const M3 &rmat, V3 w_b, V3 v_b) {
+__device__ __forceinline__ S6 ell_fluid_local(const float FFE_GLOBAL *e, V3 rpos, const M3 &rmat, V3 w_b, V3 v_b) {
   V3 w = mtv(rmat, w_b), v = mtv(rmat, v_b + cross(w_b, rpos));
   V3 plin = {e[1] * v.x, e[2] * v.y, e[3] * v.z}, pang = {e[4] * w.x, e[5] * w.y, e[6] * w.z};
   V3 f = cross(plin, w);
@@ -239,16 +239,22 @@ __device__ __forceinline__ S6 ell_fluid_local(const float *e, V3 rpos, const M3 
   return mk6(mv(rmat, t) + cross(rpos, fb), fb);
 }
 
-// mj: getimpedance
+// mj: getimpedance.  x^p: the model's solimp power is 2 (MuJoCo default); other exponents go through exp2/log2.
+__device__ __forceinline__ float pow_pos(float x, float p) {
+  if (p == 2.f) return x * x;
+  if (p == 1.f) return x;
+  if (p == 3.f) return x * x * x;
+  return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));
+}
 __device__ __forceinline__ float impedance(float dmin, float dmax, float width, float mid, float power, float pos, float margin) {
   if (dmin == dmax || width <= 1e-15f) return 0.5f * (dmin + dmax);
-  float x = fabsf((pos - margin) / width);
+  float x = fabsf((pos - margin) * __builtin_amdgcn_rcpf(width));
   if (x >= 1.f) return dmax;
   if (x <= 0.f) return dmin;
   float y;
   if (power == 1.f) y = x;
-  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
-  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  else if (x <= mid) y = pow_pos(x, power) * __builtin_amdgcn_rcpf(pow_pos(mid, power - 1.f));
+  else y = 1.f - pow_pos(1.f - x, power) * __builtin_amdgcn_rcpf(pow_pos(1.f - mid, power - 1.f));
   return dmin + y * (dmax - dmin);
 }
 
@@ -264,7 +270,7 @@ __device__ __forceinline__ unsigned long long env_rng(unsigned long long seed, u
 
 // ------------------------------------------------------------------------------------------------ per-wave context
 struct Ctx {
-  const DevModel *Mp;
+  const DevModel FFE_GLOBAL *Mp;
   Tile &T;
   int lane;
   int flags;
@@ -272,13 +278,16 @@ struct Ctx {
   float f_smooth_nb;  // passive(spring+damper) - bias + fluid per dof lane (actuation is added in stage 2)
   float qacc;         // constrained acceleration (mj: d->qacc)
   float dinv[2];      // 1 / D of this lane's dof for the two resident factorisations
+#ifdef FFE_STAMPS
+  unsigned long long st_t0, st_acc[16];
+#endif
 };
 
 // Per-lane model constants are (re)read from the lane-major tables where they are used instead of being pinned in
 // registers across the whole step: the tables are L1/L2 resident, the reads coalesce, and the register allocator is
 // left with short live ranges in the dependent loops.  The pointer is laundered so the loads are not hoisted back.
-__device__ __forceinline__ const DevModel &model(const Ctx &c) {
-  const DevModel *m = c.Mp;
+__device__ __forceinline__ const DevModel FFE_GLOBAL &model(const Ctx &c) {
+  const DevModel FFE_GLOBAL *m = c.Mp;
   asm volatile("" : "+s"(m));
   return *m;
 }
@@ -295,19 +304,35 @@ __device__ __forceinline__ const DevModel &model(const Ctx &c) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 #endif
+// Diagnostic build only (-DFFE_STAMPS): per-section shader-clock shares, summed over waves (cdna guide section 7,
+// "In-kernel stamps").  The stamped build is never timed or shipped; read its SHARES, not its length.
+#ifdef FFE_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[16] = {0}
+#define STAMP(k)                                                   \
+  do {                                                             \
+    __builtin_amdgcn_s_waitcnt(0);                                 \
+    unsigned long long st_t1 = __builtin_amdgcn_s_memtime();       \
+    c.st_acc[k] += st_t1 - c.st_t0;                                \
+    c.st_t0 = st_t1;                                               \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 // timing-only ablation switches (bench experiments; results are wrong when set)
 enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22 };
 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
 __device__ void stage1(Ctx &c) {
-  const DevModel &M = model(c);
+  const DevModel FFE_GLOBAL &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_link = lane < M.nlink, is_dof = lane < M.nv;
   const int l_dofadr = M.l_dofadr[lane], l_dofnum = M.l_dofnum[lane], l_sub = M.l_sub[lane];
   const int d_link = M.d_link[lane], d_kind = M.d_kind[lane];
   const unsigned anc_lo = M.l_anc[lane], anc_hi = M.l_anc[kLanePad + lane];  // ancestor links, nearest first, 0xff = none
+  STAMP(8);  // everything between the last stamp and a stage 1 (integration, sensors, ghost, prologue)
 
   // ---- K1: link frame in its parent (joint rotations folded in) + hinge axes in the final link frame
   if (is_link) {
@@ -372,6 +397,7 @@ __device__ void stage1(Ctx &c) {
     st10(T.cinert[lane], cin);
   }
   SYNC();
+  STAMP(0);  // kinematics + com + cinert
   // ---- dof axes in the com-centred world frame (mj: mju_dofCom)
   S6 cd = zero6();
   float qv = 0.f;
@@ -432,6 +458,7 @@ __device__ void stage1(Ctx &c) {
     st6(T.cdofd[lane], cdd);
   }
   SYNC();
+  STAMP(1);  // cdof + velocities
   // ---- A1: per-link sum of cdof_dot * qvel
   if (is_link) {
     S6 da = zero6();
@@ -475,6 +502,7 @@ __device__ void stage1(Ctx &c) {
   }
   if (is_link) st6(T.lc[lane], frc);
   SYNC();
+  STAMP(2);  // rne forward + fluid
   // ---- A3: subtree sums (links are in depth-first order, so a subtree is a contiguous range) for forces and
   //          composite inertias (mj: mj_rne backward pass, mj_crb accumulation)
   {
@@ -511,6 +539,7 @@ __device__ void stage1(Ctx &c) {
   }
   SYNC();
   // M(i,j) = cdof_j . (crb_i cdof_i) is formed directly into the factor's working copy (see factor)
+  STAMP(3);  // subtree sums + joint space
 }
 
 
@@ -525,7 +554,7 @@ __device__ void stage1(Ctx &c) {
 // (an active-set change) and leaves the Euler factor in .y untouched.
 template <bool DUAL>
 __device__ void factor(Ctx &c, float add0, float add1) {
-  const DevModel &M = model(c);
+  const DevModel FFE_GLOBAL &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
@@ -533,13 +562,27 @@ __device__ void factor(Ctx &c, float add0, float add1) {
   unsigned pr[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) pr[r] = M.pairtab[lane + r * kWave];
+  STAMP(6);
   // mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs, written straight into the working copy
   // (cdof and crb*cdof stay in LDS for the whole substep, so a refactorisation simply forms the entries again)
-  for (int e = lane; e < M.nM; e += kWave) {
-    const int i = M.m_row[e], j = M.m_col[e];
-    float m = dot6(ld6(T.cdof[j]), ld6(T.buf[i]));
-    if (i == j) m += M.d_arm[i] + ((c.flags & DBG_SKIP_MENTRIES) ? 1.f : 0.f);
-    if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
+  {
+    int ei[7], ej[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const int e = lane + r * kWave;
+      const bool ok = e < M.nM;
+      ei[r] = ok ? M.m_row[e] : 0;
+      ej[r] = ok ? M.m_col[e] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const int e = lane + r * kWave;
+      if (e < M.nM) {
+        float m = dot6(ld6(T.cdof[ej[r]]), ld6(T.buf[ei[r]]));
+        if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + ((c.flags & DBG_SKIP_MENTRIES) ? 1.f : 0.f);
+        if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
+      }
+    }
   }
   SYNC();
   if (lane < nv) {
@@ -547,6 +590,7 @@ __device__ void factor(Ctx &c, float add0, float add1) {
     if (DUAL) T.LD[d_madr].y += add1;
   }
   SYNC();
+  STAMP(4);  // M entries
   if (c.flags & DBG_SKIP_FACTOR) {
     c.dinv[0] = lane < nv ? 1.0f / T.LD[d_madr].x : 0.f;
     if (DUAL) c.dinv[1] = lane < nv ? 1.0f / T.LD[d_madr].y : 0.f;
@@ -588,13 +632,14 @@ __device__ void factor(Ctx &c, float add0, float add1) {
   } else {
     c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(T.LD[d_madr].x) : 0.f;
   }
+  STAMP(5);  // elimination
 }
 
 // mj: mj_solveLD with the factor above; the vector lives in registers (one dof per lane) and travels by readlane,
 // the factor is only read, so there is no barrier inside the two sweeps.
 template <int COMP>
 __device__ float solve(Ctx &c, float rhs) {
-  const DevModel &M = model(c);
+  const DevModel FFE_GLOBAL &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
@@ -603,6 +648,7 @@ __device__ float solve(Ctx &c, float rhs) {
   const float dinv = c.dinv[COMP];
   const float *LDc = reinterpret_cast<const float *>(T.LD) + COMP;  // entry e of this factor sits at LDc[2 e]
   if (c.flags & DBG_SKIP_SOLVE) return is_dof ? rhs * dinv : 0.f;
+  STAMP(6);  // stage-2 glue before a solve
   float x = is_dof ? rhs : 0.f;
   const int my_end = lane + d_ndesc;         // last descendant dof of this lane
   const int my_md = d_madr + d_depth;      // so that row-entry addresses become (my_md - depth_of_column)
@@ -646,6 +692,7 @@ __device__ float solve(Ctx &c, float rhs) {
     const float l0 = (lane > j && lane <= rl_i(my_end, j)) ? LDc[2 * (my_md - rl_i(dep, j))] * dinv : 0.f;
     x -= l0 * rl_f(x, j);
   }
+  STAMP(7);  // triangular solves
   return x;
 }
 
@@ -653,7 +700,7 @@ __device__ float solve(Ctx &c, float rhs) {
 // predicates and index arithmetic): used when no joint limit is instantiated, where qacc = M^-1 f and the Euler
 // acceleration (M + h B)^-1 f differ only in the factor.
 __device__ float2 solve_both(Ctx &c, float rhs) {
-  const DevModel &M = model(c);
+  const DevModel FFE_GLOBAL &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
@@ -661,6 +708,7 @@ __device__ float2 solve_both(Ctx &c, float rhs) {
   const int d_madr = M.d_madr[lane], d_depth = M.d_depth[lane], d_ndesc = M.d_ndesc[lane];
   const float di0 = c.dinv[0], di1 = c.dinv[1];
   if (c.flags & DBG_SKIP_SOLVE) return is_dof ? make_float2(rhs * di0, rhs * di1) : make_float2(0.f, 0.f);
+  STAMP(6);
   float x0 = is_dof ? rhs : 0.f, x1 = x0;
   const int my_end = lane + d_ndesc, my_md = d_madr + d_depth, dep = d_depth;
   const float2 z2 = make_float2(0.f, 0.f);
@@ -697,6 +745,7 @@ __device__ float2 solve_both(Ctx &c, float rhs) {
     x0 -= l0.x * di0 * rl_f(x0, j);
     x1 -= l0.y * di1 * rl_f(x1, j);
   }
+  STAMP(7);
   return make_float2(x0, x1);
 }
 
@@ -706,8 +755,9 @@ struct StepOut {
 
 // Stage 2 = mj_fwdActuation, mj_fwdAcceleration, mj_fwdConstraint (joint limits), accelerometer, mj_Euler.
 // `ctrl_force` is the per-dof generalized actuator force, already assembled.
-__device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long &lo_mask, unsigned long long &hi_mask, int &iters_out) {
-  const DevModel &M = model(c);
+__device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, double ghost_accel_z, unsigned long long &lo_mask,
+                     unsigned long long &hi_mask, int &iters_out) {
+  const DevModel FFE_GLOBAL &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_dof = lane < M.nv;
@@ -729,17 +779,18 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
     if (dist_lo < margin) {
       ex_lo = true;
       float imp = impedance(dmin, dmax, width, mid, power, dist_lo, margin);
-      D_lo = 1.0f / fmaxf(1e-15f, (1.f - imp) * iw / imp);
+      D_lo = imp * __builtin_amdgcn_rcpf(fmaxf(1e-30f, (1.f - imp) * iw));
       ar_lo = -B * qv - K * imp * (dist_lo - margin);
     }
     if (dist_hi < margin) {
       ex_hi = true;
       float imp = impedance(dmin, dmax, width, mid, power, dist_hi, margin);
-      D_hi = 1.0f / fmaxf(1e-15f, (1.f - imp) * iw / imp);
+      D_hi = imp * __builtin_amdgcn_rcpf(fmaxf(1e-30f, (1.f - imp) * iw));
       ar_hi = B * qv - K * imp * (dist_hi - margin);
     }
   }
   const unsigned long long ex_any = __ballot(ex_lo || ex_hi);
+  STAMP(13);  // limit instantiation
   // Primal active-set Newton on  1/2 (a-a_s)'M(a-a_s) + sum 1/2 D min(0, J a - aref)^2 : with hinge limits the Hessian
   // is M + diag(D_active), i.e. the same sparse factorisation with a different diagonal; with no limit instantiated it
   // degenerates to qacc = M^-1 qfrc_smooth.  The implicit-damping Euler solve (M + h B) reuses the same code as a final
@@ -773,6 +824,7 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
     if (act_hi) fc -= D_hi * (ar_hi + a);
     ae = want_euler ? solve<1>(c, f + fc) : a;
   }
+  STAMP(14);  // (remaining glue inside the constraint/Euler block)
   lo_mask = __ballot(act_lo);
   hi_mask = __ballot(act_hi);
   iters_out = ex_any ? iters : 0;
@@ -793,19 +845,31 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
     if (d_kind == 2) T.qpos[M.d_qadr[lane]] = qp + h * nv_;
   }
   SYNC();
-  if (lane == 0) {
-    // free joint: position in float64, orientation by mju_quatIntegrate with the body-frame angular velocity
-    T.rootpos[0] += (double)h * (double)T.qvel[0];
-    T.rootpos[1] += (double)h * (double)T.qvel[1];
-    T.rootpos[2] += (double)h * (double)T.qvel[2];
-    V3 w = {T.qvel[3], T.qvel[4], T.qvel[5]};
-    float n = sqrtf(dot(w, w));
-    Q4 q = qnormalize(Q4{T.qpos[3], T.qpos[4], T.qpos[5], T.qpos[6]});
-    if (n >= 1e-15f) {
-      V3 ax = (1.0f / n) * w;
-      q = qnormalize(qmul(q, axis_angle(ax, n * h)));
+  // Free-joint and ghost integration, one instruction stream for both: lanes 0-2 advance the root position, lanes 3-5
+  // the ghost position (float64); lane 0 / lane 1 advance the root / ghost orientation (mju_quatIntegrate with the
+  // body-frame angular velocity).  The ghost is an armature-1 free body coasting at the reference velocity.
+  if (lane < 6) {
+    const int k = lane < 3 ? lane : lane - 3;
+    if (lane < 3) T.rootpos[k] += (double)h * (double)T.qvel[k];
+    else if (with_ghost) {
+      double gv = T.ghost[7 + k];
+      if (k == 2) { gv += (double)h * ghost_accel_z; T.ghost[9] = gv; }
+      T.ghost[k] += (double)h * gv;
     }
-    T.qpos[3] = q.w; T.qpos[4] = q.x; T.qpos[5] = q.y; T.qpos[6] = q.z;
+  }
+  if (lane < 2 && (lane == 0 || with_ghost)) {
+    Q4 q;
+    V3 w;
+    if (lane == 0) { q = {T.qpos[3], T.qpos[4], T.qpos[5], T.qpos[6]}; w = {T.qvel[3], T.qvel[4], T.qvel[5]}; }
+    else { q = {(float)T.ghost[3], (float)T.ghost[4], (float)T.ghost[5], (float)T.ghost[6]}; w = {(float)T.ghost[10], (float)T.ghost[11], (float)T.ghost[12]}; }
+    const float n2 = dot(w, w);
+    q = qnormalize(q);
+    if (n2 >= 1e-30f) {
+      const float rn = __builtin_amdgcn_rsqf(n2);
+      q = qnormalize(qmul(q, axis_angle(rn * w, n2 * rn * h)));
+    }
+    if (lane == 0) { T.qpos[3] = q.w; T.qpos[4] = q.x; T.qpos[5] = q.y; T.qpos[6] = q.z; }
+    else { T.ghost[3] = q.w; T.ghost[4] = q.x; T.ghost[5] = q.y; T.ghost[6] = q.z; }
   }
   SYNC();
   return accel;
@@ -813,7 +877,7 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, unsigned long long 
 
 // mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.
 __device__ float actuation(Ctx &c, const float *ctrl_lds) {
-  const DevModel &M = model(c);
+  const DevModel FFE_GLOBAL &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   if (c.flags & FFE_NO_ACTUATION) return 0.f;
@@ -821,8 +885,12 @@ __device__ float actuation(Ctx &c, const float *ctrl_lds) {
     float ctrl = ctrl_lds[lane];
     if (M.a_cl[lane]) ctrl = fminf(fmaxf(ctrl, M.a_clo[lane]), M.a_chi[lane]);
     float len = 0.f, vel = 0.f;
-    if (M.a_trn[lane] == 0) { len = T.qpos[M.a_qadr[lane]]; vel = T.qvel[M.a_dof[lane]]; }
-    else for (int w = M.a_wrap_off[lane]; w < M.a_wrap_off[lane + 1]; w++) { len += M.w_coef[w] * T.qpos[M.w_qadr[w]]; vel += M.w_coef[w] * T.qvel[M.w_dof[w]]; }
+#pragma unroll
+    for (int w = 0; w < kMaxWrap; w++) {  // zero-padded transmission terms: independent loads, no data-dependent loop
+      const float cf = M.t_coef[w * kMaxAct + lane];
+      len += cf * T.qpos[M.t_qadr[w * kMaxAct + lane]];
+      vel += cf * T.qvel[M.t_dof[w * kMaxAct + lane]];
+    }
     float force = M.a_gain[lane] * ctrl + M.a_b0[lane] + M.a_b1[lane] * len + M.a_b2[lane] * vel;
     if (M.a_fl[lane]) force = fminf(fmaxf(force, M.a_flo[lane]), M.a_fhi[lane]);
     T.frc[lane] = force;
@@ -850,7 +918,7 @@ __device__ __noinline__ double wbpg_filter(double cf, double rate, double base, 
 }
 // argmin_i |table[i] - x| with numpy's first-minimum tie-break, across the wave (float64, bit-compatible
 // with the reference's np.argmin(np.abs(...)) on the same tables; ref: pattern_generators.py:148,179,186)
-__device__ int wave_argmin_absdiff(const double *tab, int n, double x, int lane) {
+__device__ int wave_argmin_absdiff(const double FFE_GLOBAL *tab, int n, double x, int lane) {
   double bv = 1e300;
   int bi = 0x7fffffff;
   for (int i = lane; i < n; i += kWave) {
@@ -875,9 +943,9 @@ __device__ __forceinline__ ObsLayout obs_layout(int nj, int nref) {
 
 // Observation assembly (ref: fruitfly.py:532-708 enabled set per tasks/base.py:167-168 + flight_imitation.py:84-85;
 // ref_displacement / ref_root_quat: tasks/base.py:237-261).  Returns |ref_displacement[0]| and ref_root_quat[0].
-__device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_idx, int step_counter,
+__device__ void write_obs(Ctx &c, const TaskDev FFE_GLOBAL &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_idx, int step_counter,
                           float &com_dist, Q4 &rq0) {
-  const DevModel &M = model(c);
+  const DevModel FFE_GLOBAL &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nref = K.future_steps + 1;
@@ -909,7 +977,7 @@ __device__ void write_obs(Ctx &c, const TaskDev &K, float *obs, V3 s_acc, V3 s_g
 }
 
 __device__ __forceinline__ void load_lane_consts(Ctx &c) {
-  const DevModel &M = *c.Mp;
+  const DevModel FFE_GLOBAL &M = *c.Mp;
   c.dinv[0] = c.dinv[1] = 0.f;
   for (int e = c.lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
 }
@@ -917,17 +985,23 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
 // ------------------------------------------------------------------------------------------------ the step kernel
 // One launch = one dm_env step of every env.  mode: 0 = step (auto-reset envs that ended), 1 = reset all,
 // 2 = bare physics: `nphys` mj_steps with ctrl taken verbatim from act[B][nu] (no task, no outputs) - BASELINE config 2.
-__global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(const DevModel *__restrict__ Mp, const TaskDev *__restrict__ Kp, EnvState *__restrict__ states, const float *__restrict__ act,
+__global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(const DevModel *__restrict__ Mp_, const TaskDev *__restrict__ Kp_, EnvState *__restrict__ states, const float *__restrict__ act,
                                                               float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                               float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode, int nphys) {
   __shared__ Tile T;
-  const DevModel &M = *Mp;
-  const TaskDev &K = *Kp;
+  const DevModel FFE_GLOBAL *Mp = (const DevModel FFE_GLOBAL *)Mp_;
+  const TaskDev FFE_GLOBAL *Kp = (const TaskDev FFE_GLOBAL *)Kp_;
+  const DevModel FFE_GLOBAL &M = *Mp;
+  const TaskDev FFE_GLOBAL &K = *Kp;
   const int env = blockIdx.x;
   if (env >= batch) return;
   const int lane = threadIdx.x;
   EnvState &S = states[env];
   Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}};
+#ifdef FFE_STAMPS
+  c.st_t0 = __builtin_amdgcn_s_memtime();
+  for (int k = 0; k < 16; k++) c.st_acc[k] = 0;
+#endif
   load_lane_consts(c);
   float *obs = obs_out + (size_t)env * K.obs_dim;
   const bool phys_only = (mode == 2);
@@ -1025,14 +1099,17 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   // ---- physics.  dm_control's legacy step is mj_step2 then mj_step1, so the position/velocity stage is evaluated
   //      once up front and again after every integration; buffered sensors take one sample per substep.  A reset
   //      is the same pipeline run once without actuation and without integrating (mj_forward).
+  STAMP(11);  // prologue: state load, WBPG, action mixing (or episode reset)
   const int nst = do_reset ? 1 : nsub;
 #pragma unroll 1
   for (int s = 0; s <= nst; s++) {
     if (!(c.flags & DBG_SKIP_STAGE1) || s == 0) stage1(c);
-    if (lane == 0 && (do_reset || s > 0)) {
-      V3 v = mtv(ldm(T.xmat[0]), V3{T.qvel[0], T.qvel[1], T.qvel[2]});
-      T.sens[3] += T.qvel[3]; T.sens[4] += T.qvel[4]; T.sens[5] += T.qvel[5];
-      T.sens[6] += v.x; T.sens[7] += v.y; T.sens[8] += v.z;
+    if (lane < 6 && (do_reset || s > 0)) {
+      // buffered velocity sensors at the thorax site: gyro = body-frame angular velocity, velocimeter = R^T v
+      float add;
+      if (lane < 3) add = T.xmat[0][lane] * T.qvel[0] + T.xmat[0][3 + lane] * T.qvel[1] + T.xmat[0][6 + lane] * T.qvel[2];
+      else add = T.qvel[lane];
+      T.sens[lane < 3 ? 6 + lane : lane] += add;
     }
     if (s == nst) break;
     float qa = 0.f;
@@ -1041,26 +1118,11 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       SYNC();
       qa = actuation(c, T.frc);
     }
+    STAMP(12);  // sensor accumulation + actuation
     int it = 0;
-    V3 acc = stage2(c, qa, !do_reset, lo_mask, hi_mask, it);
+    const V3 acc = stage2(c, qa, !do_reset, !do_reset && !phys_only && !(c.flags & DBG_SKIP_GHOST), K.ghost_accel_z, lo_mask, hi_mask, it);
     iters += it;
-    if (lane == 0) {
-      T.sens[0] += acc.x; T.sens[1] += acc.y; T.sens[2] += acc.z;
-      if (!do_reset && !(c.flags & DBG_SKIP_GHOST)) {
-        // ghost: armature-1 free body coasting at the reference velocity (closed form, float64)
-        double *g = T.ghost;
-        const double hh = (double)M.h;
-        g[9] += hh * K.ghost_accel_z;
-        g[0] += hh * g[7]; g[1] += hh * g[8]; g[2] += hh * g[9];
-        // orientation in float32: it only steers the 0.04 cm root->CoM lever of the tracking reward
-        V3 gw = {(float)g[10], (float)g[11], (float)g[12]};
-        float gn = sqrtf(dot(gw, gw));
-        Q4 gq = qnormalize(Q4{(float)g[3], (float)g[4], (float)g[5], (float)g[6]});
-        if (gn >= 1e-15f) gq = qnormalize(qmul(gq, axis_angle((1.0f / gn) * gw, gn * M.h)));
-        double q0 = gq.w, q1 = gq.x, q2 = gq.y, q3 = gq.z;
-        g[3] = q0; g[4] = q1; g[5] = q2; g[6] = q3;
-      }
-    }
+    if (lane < 3) T.sens[lane] += lane == 0 ? acc.x : (lane == 1 ? acc.y : acc.z);
     if (do_reset) break;
   }
   SYNC();
@@ -1106,6 +1168,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   if (lane < 7) S.ghost[lane] = T.ghost[lane];
   if (lane == 0) S.episode = episode;
   }  // !phys_only
+  STAMP(9);  // epilogue: observation, reward, termination
   // ---- store state
   if (lane < kMaxDof + 4) { S.qpos[lane] = T.qpos[lane]; S.qvel[lane] = T.qvel[lane]; }
   if (lane == 0) {
@@ -1114,6 +1177,10 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.solver_iters = iters;
     S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
   }
+#ifdef FFE_STAMPS
+  STAMP(10);
+  if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);
+#endif
 }
 
 __global__ void init_states_kernel(EnvState *states, int batch) {
@@ -1242,13 +1309,13 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
     K.pad_first_obs = t.pad_first_obs; K.flags = t.physics_flags;
     K.base_freq = t.wb_base_freq; K.rel_range = t.wb_rel_range; K.rate = t.wb_rate; K.dt_ctrl = t.wb_dt_ctrl;
     K.terminal_com_dist = t.terminal_com_dist; K.ghost_accel_z = t.ghost_accel_z;
-    K.beat_freqs = upload(h.get(), t.wb_beat_freqs, (size_t)t.wb_nfreq);
-    K.tab_off = upload(h.get(), t.wb_tab_off, (size_t)t.wb_nfreq + 1);
-    K.phase = upload(h.get(), t.wb_phase, (size_t)rows);
-    K.phase_frac = upload(h.get(), frac.data(), frac.size());
-    K.traj = upload(h.get(), trajf.data(), trajf.size());
-    K.ref_qpos = upload(h.get(), t.ref_qpos, (size_t)t.ntraj * t.traj_len * 7);
-    K.ref_qvel = upload(h.get(), t.ref_qvel, (size_t)t.ntraj * t.traj_len * 6);
+    set_off(K.beat_freqs, (size_t)upload(h.get(), t.wb_beat_freqs, (size_t)t.wb_nfreq));
+    set_off(K.tab_off, (size_t)upload(h.get(), t.wb_tab_off, (size_t)t.wb_nfreq + 1));
+    set_off(K.phase, (size_t)upload(h.get(), t.wb_phase, (size_t)rows));
+    set_off(K.phase_frac, (size_t)upload(h.get(), frac.data(), frac.size()));
+    set_off(K.traj, (size_t)upload(h.get(), trajf.data(), trajf.size()));
+    set_off(K.ref_qpos, (size_t)upload(h.get(), t.ref_qpos, (size_t)t.ntraj * t.traj_len * 7));
+    set_off(K.ref_qvel, (size_t)upload(h.get(), t.ref_qvel, (size_t)t.ntraj * t.traj_len * 6));
     K.seed = seed; K.env_id_base = env_id_base;
     K.obs_dim = 12 + 2 * h->dm.nobsj + 7 * (t.future_steps + 1);
     h->host.nobs = K.obs_dim;
@@ -1365,6 +1432,14 @@ int ffe_time_steps(ffe_handle h, const float *act, float *obs, float *rew, float
   *ms = total / (float)iters;
   return 0;
 }
+
+#ifdef FFE_STAMPS
+int ffe_debug_read_stamps(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 int ffe_test_quat(int op, const float *a, const float *b, float *out, int n, void *stream) {
   if (!a || !b || !out || n <= 0) return -1;
