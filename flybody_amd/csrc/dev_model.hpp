@@ -18,8 +18,10 @@
 // memory wait counters together).  Declaring them global on the device side makes every table read a global_load.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FFE_GLOBAL __attribute__((address_space(1)))
+#define FFE_CONST __attribute__((address_space(4)))  // read-only struct of table pointers: uniform fields come by s_load
 #else
 #define FFE_GLOBAL
+#define FFE_CONST
 #endif
 
 namespace ffe {

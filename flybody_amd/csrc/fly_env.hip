@@ -270,7 +270,7 @@ __device__ __forceinline__ unsigned long long env_rng(unsigned long long seed, u
 
 // ------------------------------------------------------------------------------------------------ per-wave context
 struct Ctx {
-  const DevModel FFE_GLOBAL *Mp;
+  const DevModel FFE_CONST *Mp;
   Tile &T;
   int lane;
   int flags;
@@ -286,8 +286,8 @@ struct Ctx {
 // Per-lane model constants are (re)read from the lane-major tables where they are used instead of being pinned in
 // registers across the whole step: the tables are L1/L2 resident, the reads coalesce, and the register allocator is
 // left with short live ranges in the dependent loops.  The pointer is laundered so the loads are not hoisted back.
-__device__ __forceinline__ const DevModel FFE_GLOBAL &model(const Ctx &c) {
-  const DevModel FFE_GLOBAL *m = c.Mp;
+__device__ __forceinline__ const DevModel FFE_CONST &model(const Ctx &c) {
+  const DevModel FFE_CONST *m = c.Mp;
   asm volatile("" : "+s"(m));
   return *m;
 }
@@ -325,7 +325,7 @@ enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
 __device__ void stage1(Ctx &c) {
-  const DevModel FFE_GLOBAL &M = model(c);
+  const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_link = lane < M.nlink, is_dof = lane < M.nv;
@@ -554,7 +554,7 @@ __device__ void stage1(Ctx &c) {
 // (an active-set change) and leaves the Euler factor in .y untouched.
 template <bool DUAL>
 __device__ void factor(Ctx &c, float add0, float add1) {
-  const DevModel FFE_GLOBAL &M = model(c);
+  const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
@@ -639,7 +639,7 @@ __device__ void factor(Ctx &c, float add0, float add1) {
 // the factor is only read, so there is no barrier inside the two sweeps.
 template <int COMP>
 __device__ float solve(Ctx &c, float rhs) {
-  const DevModel FFE_GLOBAL &M = model(c);
+  const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
@@ -700,7 +700,7 @@ __device__ float solve(Ctx &c, float rhs) {
 // predicates and index arithmetic): used when no joint limit is instantiated, where qacc = M^-1 f and the Euler
 // acceleration (M + h B)^-1 f differ only in the factor.
 __device__ float2 solve_both(Ctx &c, float rhs) {
-  const DevModel FFE_GLOBAL &M = model(c);
+  const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
@@ -757,7 +757,7 @@ struct StepOut {
 // `ctrl_force` is the per-dof generalized actuator force, already assembled.
 __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, double ghost_accel_z, unsigned long long &lo_mask,
                      unsigned long long &hi_mask, int &iters_out) {
-  const DevModel FFE_GLOBAL &M = model(c);
+  const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const bool is_dof = lane < M.nv;
@@ -877,7 +877,7 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, do
 
 // mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.
 __device__ float actuation(Ctx &c, const float *ctrl_lds) {
-  const DevModel FFE_GLOBAL &M = model(c);
+  const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   if (c.flags & FFE_NO_ACTUATION) return 0.f;
@@ -943,9 +943,9 @@ __device__ __forceinline__ ObsLayout obs_layout(int nj, int nref) {
 
 // Observation assembly (ref: fruitfly.py:532-708 enabled set per tasks/base.py:167-168 + flight_imitation.py:84-85;
 // ref_displacement / ref_root_quat: tasks/base.py:237-261).  Returns |ref_displacement[0]| and ref_root_quat[0].
-__device__ void write_obs(Ctx &c, const TaskDev FFE_GLOBAL &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_idx, int step_counter,
+__device__ void write_obs(Ctx &c, const TaskDev FFE_CONST &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_idx, int step_counter,
                           float &com_dist, Q4 &rq0) {
-  const DevModel FFE_GLOBAL &M = model(c);
+  const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
   const int nref = K.future_steps + 1;
@@ -977,7 +977,7 @@ __device__ void write_obs(Ctx &c, const TaskDev FFE_GLOBAL &K, float *obs, V3 s_
 }
 
 __device__ __forceinline__ void load_lane_consts(Ctx &c) {
-  const DevModel FFE_GLOBAL &M = *c.Mp;
+  const DevModel FFE_CONST &M = *c.Mp;
   c.dinv[0] = c.dinv[1] = 0.f;
   for (int e = c.lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
 }
@@ -989,10 +989,10 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
                                                               float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                               float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode, int nphys) {
   __shared__ Tile T;
-  const DevModel FFE_GLOBAL *Mp = (const DevModel FFE_GLOBAL *)Mp_;
-  const TaskDev FFE_GLOBAL *Kp = (const TaskDev FFE_GLOBAL *)Kp_;
-  const DevModel FFE_GLOBAL &M = *Mp;
-  const TaskDev FFE_GLOBAL &K = *Kp;
+  const DevModel FFE_CONST *Mp = (const DevModel FFE_CONST *)Mp_;
+  const TaskDev FFE_CONST *Kp = (const TaskDev FFE_CONST *)Kp_;
+  const DevModel FFE_CONST &M = *Mp;
+  const TaskDev FFE_CONST &K = *Kp;
   const int env = blockIdx.x;
   if (env >= batch) return;
   const int lane = threadIdx.x;
