@@ -39,6 +39,11 @@ struct alignas(64) EnvState {
   float qpos[kMaxDof + 4];  // [0..2] unused (root position is held in float64 above), [3..6] root quat, hinges
   float qvel[kMaxDof + 4];
   int wb_step, wb_freq_idx, step_counter, traj_idx, needs_reset, nactive, solver_iters, forced_traj;
+  // Position/velocity-stage results of the state above (dof axes, crb*axes, smooth joint forces, root frame, CoM): the
+  // last stage-1 evaluation of a control step is exactly the first one of the next, so it is carried over instead of
+  // being recomputed (bit-identical by construction; dropped whenever the state is written from outside).
+  int s1_valid, pad_[15];
+  float s1_cdof[kMaxDof * 6], s1_buf[kMaxDof * 6], s1_f[kLanePad], s1_misc[16];
 };
 
 struct TaskDev {
@@ -320,7 +325,7 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(k) do {} while (0)
 #endif
 // timing-only ablation switches (bench experiments; results are wrong when set)
-enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22 };
+enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22, DBG_NO_CARRY = 1 << 23 };
 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
@@ -1100,10 +1105,17 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   //      once up front and again after every integration; buffered sensors take one sample per substep.  A reset
   //      is the same pipeline run once without actuation and without integrating (mj_forward).
   STAMP(11);  // prologue: state load, WBPG, action mixing (or episode reset)
+  const bool have_saved = !do_reset && S.s1_valid != 0 && !(c.flags & DBG_NO_CARRY);
   const int nst = do_reset ? 1 : nsub;
 #pragma unroll 1
   for (int s = 0; s <= nst; s++) {
-    if (!(c.flags & DBG_SKIP_STAGE1) || s == 0) stage1(c);
+    if (s == 0 && have_saved) {
+      for (int e = lane; e < kMaxDof * 6; e += kWave) { (&T.cdof[0][0])[e] = S.s1_cdof[e]; (&T.buf[0][0])[e] = S.s1_buf[e]; }
+      c.f_smooth_nb = S.s1_f[lane];
+      if (lane < 9) T.xmat[0][lane] = S.s1_misc[lane];
+      c.com = {S.s1_misc[9], S.s1_misc[10], S.s1_misc[11]};
+      SYNC();
+    } else if (!(c.flags & DBG_SKIP_STAGE1) || s == 0) stage1(c);
     if (lane < 6 && (do_reset || s > 0)) {
       // buffered velocity sensors at the thorax site: gyro = body-frame angular velocity, velocimeter = R^T v
       float add;
@@ -1177,6 +1189,11 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.solver_iters = iters;
     S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
   }
+  // carry the final stage-1 results to the next launch (a reset's single evaluation is that of the FIRST state)
+  for (int e = lane; e < kMaxDof * 6; e += kWave) { S.s1_cdof[e] = (&T.cdof[0][0])[e]; S.s1_buf[e] = (&T.buf[0][0])[e]; }
+  S.s1_f[lane] = c.f_smooth_nb;
+  if (lane < 9) S.s1_misc[lane] = T.xmat[0][lane];
+  if (lane == 0) { S.s1_misc[9] = c.com.x; S.s1_misc[10] = c.com.y; S.s1_misc[11] = c.com.z; S.s1_valid = 1; }
 #ifdef FFE_STAMPS
   STAMP(10);
   if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);
@@ -1204,7 +1221,7 @@ __global__ void set_state_kernel(EnvState *states, const double *qpos, const dou
   EnvState &S = states[env];
   if (lane < nq) { if (lane < 3) S.rootpos[lane] = qpos[(size_t)env * nq + lane]; else S.qpos[lane] = (float)qpos[(size_t)env * nq + lane]; }
   if (lane < nv) S.qvel[lane] = (float)qvel[(size_t)env * nv + lane];
-  if (lane == 0) { S.lo_mask = 0; S.hi_mask = 0; }
+  if (lane == 0) { S.lo_mask = 0; S.hi_mask = 0; S.s1_valid = 0; }
 }
 __global__ void get_task_state_kernel(const EnvState *states, int *ints, double *reals, int batch) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -430,3 +430,26 @@ def test_single_env_and_full_range_actions(torch_mod, wb_tables, ref_traj):
     assert stats["compared"] >= 140
     assert errs["obs"].max() < TOL_OBS_1STEP and errs["reward"].max() < TOL_REWARD_1STEP
     env.close()
+
+
+def test_stage1_carry_over_is_bit_identical(torch_mod, wb_tables, ref_traj):
+    """Carrying the last position/velocity-stage evaluation of a step into the next launch must not change a bit
+    compared with recomputing it (flag 1<<23 disables the carry)."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+
+    torch = torch_mod
+    outs = []
+    for flags in (0, 1 << 23):
+        env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=256, seed=2, physics_flags=flags)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        hist = []
+        for k in range(150):  # long enough for episodes to end and restart
+            a = ((torch.rand(256, 12, device="cuda", generator=g) * 2 - 1) * 0.5).contiguous()
+            ts = env.step(a)
+            if k % 10 == 9:
+                hist.append((env.flat_observation.clone(), ts.reward.clone(), ts.step_type.clone()))
+        outs.append(hist)
+        env.close()
+    for (o0, r0, s0), (o1, r1, s1) in zip(*outs):
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(s0, s1)
