@@ -79,6 +79,38 @@ def cpu_baseline(target_seconds=8.0):
                       f"(single-core {per_core:.0f} env-steps/s; pool wall {time.perf_counter() - t0:.1f}s)"}
 
 
+class _FakeEnv:
+    """Stand-in with the BatchedFlyEnv surface on CPU tensors: lets the tests rehearse the multi-process control flow
+    (sharding, double-buffered gather, barriers, max-over-ranks timing) with gloo.  Never used for a reported number."""
+
+    def __init__(self, B):
+        import types
+
+        import numpy as np
+        import torch
+
+        self._t, self.B = torch, B
+        self.spec = types.SimpleNamespace(obs_dim=104, nsub=4, action_dim=12)
+        self._spec = types.SimpleNamespace(minimum=-np.ones(12, np.float32), maximum=np.ones(12, np.float32), shape=(12,))
+        self.flat_observation = torch.zeros(B, 104)
+
+    def action_spec(self):
+        return self._spec
+
+    def reset(self):
+        pass
+
+    def step(self, a):
+        import types
+
+        t = self._t
+        self.flat_observation = a.sum(1, keepdim=True).expand(self.B, 104).contiguous()
+        return types.SimpleNamespace(reward=t.ones(self.B), discount=t.ones(self.B), step_type=t.ones(self.B, dtype=t.int32))
+
+    def time_steps(self, a, n):
+        return 1.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,19 +135,28 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from flybody_amd import fly_envs
-
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    fake = os.environ.get("FLYBODY_BENCH_FAKE") == "1"  # CPU rehearsal of the N>1 control flow (tests only)
+    if fake:
+        dev = torch.device("cpu")
+        backend = "gloo"
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        backend = "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({} if fake else {"device_id": dev}))
+
+    from flybody_amd.distributed import TimestepGather, shard
 
     B = args.envs_per_gpu
-    from flybody_amd.distributed import shard
-
     env_id_base, _ = shard(rank, world, B)
-    env = fly_envs.flight_imitation(batch_size=B, device=local_rank, random_state=0, env_id_base=env_id_base)
+    if fake:
+        env = _FakeEnv(B)
+    else:
+        from flybody_amd import fly_envs
+
+        env = fly_envs.flight_imitation(batch_size=B, device=local_rank, random_state=0, env_id_base=env_id_base)
     spec = env.action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
     hi = torch.tensor(spec.maximum, device=dev)
@@ -123,26 +164,40 @@ def main():
     npool = 16
     acts = [(lo + (hi - lo) * torch.rand(B, spec.shape[0], device=dev, generator=g)).contiguous() for _ in range(npool)]
 
-    # the per-step gather of everything a central learner consumes: one RCCL call per step
-    from flybody_amd.distributed import TimestepGather
-
-    gather = TimestepGather(B, env.spec.obs_dim, dev, world, rank)
+    # The per-step gather of everything a central learner consumes: one RCCL call per step,
+    # double-buffered so that the gather of step k travels over xGMI while step k+1 is being simulated.
+    gathers = [TimestepGather(B, env.spec.obs_dim, dev, world, rank) for _ in range(2)]
+    works = [None, None]
 
     def one_step(k):
         ts = env.step(acts[k % npool])
         if world > 1:
-            gather(env.flat_observation, ts.reward, ts.discount, ts.step_type)
+            i = k & 1
+            if works[i] is not None:
+                works[i].wait()
+            works[i] = gathers[i](env.flat_observation, ts.reward, ts.discount, ts.step_type, async_op=True)
         return ts
+
+    def drain():
+        for i in range(2):
+            if works[i] is not None:
+                works[i].wait()
+                works[i] = None
+
+    def sync():
+        if not fake:
+            torch.cuda.synchronize(dev)
 
     env.reset()
     for k in range(args.warmup):
         one_step(k)
 
     def fence():
-        torch.cuda.synchronize(dev)
+        drain()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
     fence()
     t0 = time.perf_counter()
@@ -157,9 +212,20 @@ def main():
 
     # dominant kernel: mean launch duration by HIP events on the launch stream, same workload
     k_ms = env.time_steps(acts[0], min(args.steps, 100))
-    torch.cuda.synchronize(dev)
+    sync()
 
     if rank == 0:
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate
+        # FETCH_SIZE / WRITE_SIZE runs; KiB units; read side doubled per the gfx950 note in MI355X_MICROARCH.md - an
+        # upper bound here, since these are 4-byte-per-lane reads, not the wide streams the x2 was calibrated on)
+        traffic, traffic_src = None, None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_final_kernel.json")
+        if os.path.exists(pj) and B == ENVS_PER_GPU and not fake:
+            with open(pj) as f:
+                pm = json.load(f)
+            if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                traffic = int((2 * pm["FETCH_SIZE"]["median"] + pm["WRITE_SIZE"]["median"]) * 1024)
+                traffic_src = "profiles/r01_pmc_final_kernel.json (2*FETCH_SIZE + WRITE_SIZE, per launch)"
         total_env_steps = world * B * args.steps
         value = total_env_steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * B / (k_ms * 1e-3) / 1e9
@@ -172,7 +238,7 @@ def main():
                        "envs_per_gpu": B, "global_batch": world * B, "parallelism": f"env-sharded x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
                        "actions": "uniform over the raw action spec (canonical U(-1,1)), resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "flight_step_kernel", "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
                          "note": "fused wave-per-env step keeps state on chip; VALU/LDS-latency bound, not HBM bound (DESIGN.md)"},

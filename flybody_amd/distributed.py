@@ -26,14 +26,19 @@ class TimestepGather:
         self.pack = torch.empty(batch, obs_dim + 3, dtype=torch.float32, device=device)
         self.out = [torch.empty_like(self.pack) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    def __call__(self, obs, reward, discount, step_type):
+    def __call__(self, obs, reward, discount, step_type, async_op: bool = False):
+        """Packs and gathers.  With `async_op` the collective runs on RCCL's own stream and the returned work handle
+        must be waited on before this object is used again (double-buffer two of them to overlap the gather of step k
+        with the physics of step k+1)."""
         p = self.pack
         p[:, : self.obs_dim] = obs
         p[:, -3] = reward
         p[:, -2] = discount
         p[:, -1] = step_type.to(torch.float32)
         if self.world > 1:
-            dist.gather(p, self.out, dst=0)
+            work = dist.gather(p, self.out, dst=0, async_op=async_op)
+            if async_op:
+                return work
         return self.out if self.rank == 0 else None
 
     @staticmethod

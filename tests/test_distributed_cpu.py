@@ -68,3 +68,26 @@ def test_episode_draws_do_not_depend_on_the_sharding():
     a = [O.rng_u64(7, 40, ep, 0) for ep in range(4)]
     b = [O.rng_u64(7, 32 + 8, ep, 0) for ep in range(4)]
     assert a == b and len(set(a)) == 4
+
+
+@pytest.mark.timeout(300)
+def test_bench_multiprocess_control_flow_on_gloo():
+    """bench.py's N>1 path (env-id sharding, double-buffered async gather, barriers, max-over-ranks timing, one JSON
+    line from rank 0) rehearsed with 2 gloo ranks and a stand-in env on CPU tensors."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, FLYBODY_BENCH_FAKE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--envs-per-gpu", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak" and d["steps"] == 6
+    assert "roofline" in d and "cpu_baseline" not in d
