@@ -54,7 +54,7 @@ def _cpu_worker(args):
     return steps, time.perf_counter() - t0
 
 
-def cpu_baseline(target_seconds=8.0):
+def cpu_baseline(target_seconds=20.0):
     """Oracle ("port") on all host cores, one env per process as the reference runs its actors
     (train_dmpo_ray.py:432-452).  Must run before this process touches the GPU (fork)."""
     import multiprocessing as mp
