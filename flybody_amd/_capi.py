@@ -24,6 +24,7 @@ class FlightTask(C.Structure):
         ("ntraj", C.c_int32), ("traj_len", C.c_int32), ("ref_qpos", C.POINTER(C.c_double)), ("ref_qvel", C.POINTER(C.c_double)),
         ("future_steps", C.c_int32), ("time_limit_steps", C.c_int32), ("terminal_com_dist", C.c_double),
         ("ghost_accel_z", C.c_double), ("pad_first_obs", C.c_int32), ("physics_flags", C.c_int32),
+        ("canonical_actions", C.c_int32), ("clip_actions", C.c_int32),
     ]
 
 

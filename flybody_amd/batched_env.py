@@ -36,7 +36,7 @@ class BatchedFlyEnv:
 
     def __init__(self, wbpg, ref_qpos, ref_qvel, *, batch_size: int, device: int = 0, seed: int = 0, env_id_base: int = 0,
                  future_steps: int = 5, time_limit: float = 0.6, terminal_com_dist: float = 2.0, pad_first_obs: bool = False,
-                 physics_flags: int = 0, blob_path: str = FLIGHT_BLOB):
+                 physics_flags: int = 0, canonical_actions: bool = False, clip_actions: bool = False, blob_path: str = FLIGHT_BLOB):
         import json
 
         import torch
@@ -70,13 +70,14 @@ class BatchedFlyEnv:
             wb_rate=wbpg.rate, wb_dt_ctrl=wbpg.dt_ctrl, ntraj=n, traj_len=t, ref_qpos=dp(k["rq"]), ref_qvel=dp(k["rv"]),
             future_steps=future_steps, time_limit_steps=int(round(time_limit / wbpg.dt_ctrl)),
             terminal_com_dist=float(terminal_com_dist), ghost_accel_z=ghost_accel_z, pad_first_obs=int(pad_first_obs),
-            physics_flags=int(physics_flags))
+            physics_flags=int(physics_flags), canonical_actions=int(canonical_actions), clip_actions=int(clip_actions))
         h = C.c_void_p()
         rc = self._L.ffe_create_flight(blob, len(blob), C.byref(task), self.batch_size, device, seed, env_id_base, C.byref(h))
         if rc != 0:
             raise RuntimeError("ffe_create_flight: " + self._L.ffe_last_error(None).decode())
         self._h = h
         self.ghost_accel_z = ghost_accel_z
+        self.canonical_actions = bool(canonical_actions)
         self.spec = _capi.Spec()
         self._check(self._L.ffe_spec(self._h, C.byref(self.spec)))
         s = self.spec
@@ -141,8 +142,14 @@ class BatchedFlyEnv:
         return self._timestep()
 
     def action_spec(self):
+        if self.canonical_actions:  # acme CanonicalSpecWrapper: every action dimension spans [-1, 1]
+            return BoundedArray((self.spec.action_dim,), np.float32, -1.0, 1.0, name="\t".join(self._meta["action_names"]))
         return BoundedArray((self.spec.action_dim,), np.float32, self._action_min, self._action_max,
                             name="\t".join(self._meta["action_names"]))
+
+    def raw_action_bounds(self):
+        """(minimum, maximum) of the un-wrapped action spec (`fruitfly.py:496-526`)."""
+        return self._action_min.copy(), self._action_max.copy()
 
     def observation_spec(self):
         return collections.OrderedDict((k, Array(shape, np.float32, name=k)) for k, (_, shape) in self._layout.items())

@@ -47,7 +47,8 @@ struct alignas(64) EnvState {
 };
 
 struct TaskDev {
-  int nfreq, ntraj, traj_len, future_steps, time_limit_steps, pad_first_obs, flags, obs_dim;
+  int nfreq, ntraj, traj_len, future_steps, time_limit_steps, pad_first_obs, flags, obs_dim, canonical, clip;
+  float act_lo[16], act_hi[16];
   double base_freq, rel_range, rate, dt_ctrl, terminal_com_dist, ghost_accel_z;
   const double FFE_GLOBAL *beat_freqs, *phase, *phase_frac, *ref_qpos, *ref_qvel;
   const float FFE_GLOBAL *traj;
@@ -1065,8 +1066,17 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     SYNC();
     // before_step (ref: flight_imitation.py:149-167, base.py:190-193, fruitfly.py:480-492)
     const float *a_in = act + (size_t)env * M.naction;
-    float act_user = a_in[M.user_action];
-    if (!(act_user == act_user)) act_user = 0.f;
+    // acme CanonicalSpecWrapper folded in (ref: train_dmpo_ray.py:128-129; tasks/task_utils.py:53-76 canonical2real)
+    auto read_action = [&](int k) -> float {
+      float v = a_in[k];
+      if (!(v == v)) v = 0.f;  // NaN scrub
+      if (K.canonical) {
+        if (K.clip) v = fminf(fmaxf(v, -1.f), 1.f);
+        v = 0.5f * (v + 1.f) * (K.act_hi[k] - K.act_lo[k]) + K.act_lo[k];
+      }
+      return v;
+    };
+    const float act_user = read_action(M.user_action);
     {
       // ref: pattern_generators.py:159-191 step
       int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
@@ -1082,9 +1092,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     }
     if (lane < M.nu) {
       int ai = M.a_action[lane];
-      float v = ai >= 0 ? a_in[ai] : 0.f;
-      if (!(v == v)) v = 0.f;
-      T.ctrl[lane] = v;
+      T.ctrl[lane] = ai >= 0 ? read_action(ai) : 0.f;
     }
     SYNC();
     if (lane < M.nwing) {
@@ -1323,7 +1331,8 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
     for (size_t i = 0; i < trajf.size(); i++) trajf[i] = (float)t.wb_traj[i];
     TaskDev &K = h->task;
     K.nfreq = t.wb_nfreq; K.ntraj = t.ntraj; K.traj_len = t.traj_len; K.future_steps = t.future_steps; K.time_limit_steps = t.time_limit_steps;
-    K.pad_first_obs = t.pad_first_obs; K.flags = t.physics_flags;
+    K.pad_first_obs = t.pad_first_obs; K.flags = t.physics_flags; K.canonical = t.canonical_actions; K.clip = t.clip_actions;
+    for (int k = 0; k < 16; k++) { K.act_lo[k] = k < h->dm.naction ? h->host.action_min[k] : 0.f; K.act_hi[k] = k < h->dm.naction ? h->host.action_max[k] : 0.f; }
     K.base_freq = t.wb_base_freq; K.rel_range = t.wb_rel_range; K.rate = t.wb_rate; K.dt_ctrl = t.wb_dt_ctrl;
     K.terminal_com_dist = t.terminal_com_dist; K.ghost_accel_z = t.ghost_accel_z;
     set_off(K.beat_freqs, (size_t)upload(h.get(), t.wb_beat_freqs, (size_t)t.wb_nfreq));

@@ -52,6 +52,10 @@ typedef struct {
   double ghost_accel_z;     /* gravity felt by the armature-1 ghost, cm/s^2 */
   int32_t pad_first_obs;    /* 0 = dm_control zero-padded sensor buffers at reset */
   int32_t physics_flags;    /* FFE_NO_* */
+  /* acme.wrappers.CanonicalSpecWrapper folded in (train_dmpo_ray.py:128-129; same map as tasks/task_utils.py:53-76
+   * canonical2real): actions arrive in [-1,1] and are mapped to lo + (a+1)/2 (hi-lo); optional clip to [-1,1] first */
+  int32_t canonical_actions;
+  int32_t clip_actions;
 } ffe_flight_task;
 
 typedef struct {

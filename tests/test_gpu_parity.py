@@ -453,3 +453,28 @@ def test_stage1_carry_over_is_bit_identical(torch_mod, wb_tables, ref_traj):
         env.close()
     for (o0, r0, s0), (o1, r1, s1) in zip(*outs):
         assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(s0, s1)
+
+
+def test_canonical_action_wrapper_folded_in(torch_mod, wb_tables, ref_traj):
+    """canonical_actions=True == the raw env fed canonical2real(a) (tasks/task_utils.py:53-76; acme CanonicalSpecWrapper
+    as applied at train_dmpo_ray.py:128-129); the spec then spans [-1, 1]."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+
+    torch = torch_mod
+    B = 32
+    raw = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=4)
+    can = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=4, canonical_actions=True, clip_actions=True)
+    spec = can.action_spec()
+    assert (spec.minimum == -1).all() and (spec.maximum == 1).all()
+    lo, hi = raw.raw_action_bounds()
+    raw.reset(); can.reset()
+    rng = np.random.RandomState(0)
+    for _ in range(10):
+        a = rng.uniform(-1.3, 1.3, (B, 12)).astype(np.float32)              # some entries need the clip
+        real = (0.5 * (np.clip(a, -1, 1) + 1) * (hi - lo) + lo).astype(np.float32)   # canonical2real in float32
+        t0 = raw.step(torch.tensor(real, device="cuda"))
+        o0 = raw.flat_observation.clone()
+        t1 = can.step(torch.tensor(a, device="cuda"))
+        assert torch.allclose(o0, can.flat_observation, rtol=0, atol=2e-4 * float(o0.abs().max()))
+        assert torch.allclose(t0.reward, t1.reward, atol=1e-6) and torch.equal(t0.step_type, t1.step_type)
+    raw.close(); can.close()
