@@ -125,9 +125,27 @@ __device__ __forceinline__ M3 mm(const M3 &a, const M3 &b) {
           a.m6 * b.m0 + a.m7 * b.m3 + a.m8 * b.m6, a.m6 * b.m1 + a.m7 * b.m4 + a.m8 * b.m7, a.m6 * b.m2 + a.m7 * b.m5 + a.m8 * b.m8};
 }
 __device__ __forceinline__ V3 qrot(Q4 q, V3 v) { return mv(q2m(q), v); }  // mj: mju_rotVecQuat
+// sin/cos of a half joint angle.  Joint ranges keep |h| below ~1.6 rad (head twist +-3, wing pitch 2.92), where the
+// Taylor polynomials below are accurate to 2e-7 (sin, degree 11) and 2e-8 (cos, degree 12); anything larger takes
+// the library path.
+__device__ __forceinline__ void sincos_half(float h, float *s, float *c) {
+  if (fabsf(h) > 1.7f) { sincosf(h, s, c); return; }
+  const float x2 = h * h;
+  float ps = fmaf(x2, -2.50521084e-8f, 2.75573192e-6f);
+  ps = fmaf(x2, ps, -1.98412698e-4f);
+  ps = fmaf(x2, ps, 8.33333333e-3f);
+  ps = fmaf(x2, ps, -1.66666667e-1f);
+  *s = fmaf(h * x2, ps, h);
+  float pc = fmaf(x2, 2.08767570e-9f, -2.75573192e-7f);
+  pc = fmaf(x2, pc, 2.48015873e-5f);
+  pc = fmaf(x2, pc, -1.38888889e-3f);
+  pc = fmaf(x2, pc, 4.16666667e-2f);
+  pc = fmaf(x2, pc, -0.5f);
+  *c = fmaf(x2, pc, 1.0f);
+}
 __device__ __forceinline__ Q4 axis_angle(V3 ax, float ang) {
   float s, c;
-  sincosf(0.5f * ang, &s, &c);
+  sincos_half(0.5f * ang, &s, &c);
   return {c, ax.x * s, ax.y * s, ax.z * s};
 }
 __device__ __forceinline__ S6 operator+(S6 a, S6 b) { return {a.a0 + b.a0, a.a1 + b.a1, a.a2 + b.a2, a.l0 + b.l0, a.l1 + b.l1, a.l2 + b.l2}; }
@@ -368,20 +386,29 @@ __device__ void stage1(Ctx &c) {
   V3 xp = {0.f, 0.f, 0.f}, xip = {0.f, 0.f, 0.f};
   M3 xm = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, xim = xm;
   float mass = 0.f;
-  if (is_link) {
-    const float *o = T.lT[lane];
-    V3 p = {o[0], o[1], o[2]};
-    Q4 q = {o[3], o[4], o[5], o[6]};
+  // Pointer doubling over the ancestor chain: after round r a link's frame is expressed in its 2^(r+1)-th ancestor,
+  // so 3 rounds (LDS hand-offs) replace a walk of up to 7 dependent compositions.
+  V3 kp = {0.f, 0.f, 0.f};
+  Q4 kq = {1.f, 0.f, 0.f, 0.f};
+  if (is_link) { const float *o = T.lT[lane]; kp = {o[0], o[1], o[2]}; kq = {o[3], o[4], o[5], o[6]}; }
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int a = (int)(((it < 4 ? anc_lo : anc_hi) >> (8 * (it & 3))) & 0xffu);
-      if (a != 0xff) {
-        const float *oa = T.lT[a];
-        Q4 qa = {oa[3], oa[4], oa[5], oa[6]};
-        p = V3{oa[0], oa[1], oa[2]} + qrot(qa, p);
-        q = qmul(qa, q);
-      }
+  for (int r = 0; r < 3; r++) {
+    const int a = (int)((anc_lo >> (8 * ((1 << r) - 1))) & 0xffu);  // 1st, 2nd, 4th ancestor
+    if (is_link && a != 0xff) {
+      const float *oa = T.lT[a];
+      const Q4 qa = {oa[3], oa[4], oa[5], oa[6]};
+      kp = V3{oa[0], oa[1], oa[2]} + qrot(qa, kp);
+      kq = qmul(qa, kq);
     }
+    SYNC();
+    if (r < 2) {
+      if (is_link) { float *o = T.lT[lane]; o[0] = kp.x; o[1] = kp.y; o[2] = kp.z; o[3] = kq.w; o[4] = kq.x; o[5] = kq.y; o[6] = kq.z; }
+      SYNC();
+    }
+  }
+  if (is_link) {
+    V3 p = kp;
+    Q4 q = kq;
     q = qnormalize(q);
     xp = p;
     xm = q2m(q);
