@@ -27,9 +27,9 @@
 namespace ffe {
 
 constexpr int kWave = 64;
-constexpr int kMaxLink = 20;  // LDS capacity (flight model: 19)
-constexpr int kMaxDof = 44;   // LDS capacity (flight model: 42)
-constexpr int kMaxM = 424;    // LDS capacity (flight model: 421)
+constexpr int kMaxLink = 19;  // LDS capacity, sized to the flight model (19 links)
+constexpr int kMaxDof = 42;   // LDS capacity (flight model: 42 dofs)
+constexpr int kMaxM = 422;    // LDS capacity (flight model: 421 entries)
 constexpr int kMaxAct = 16;
 constexpr int kMaxWrap = 8;   // transmission terms per actuator (joint: 1, fixed tendon: its joints)
 constexpr int kMaxObsJ = 32;

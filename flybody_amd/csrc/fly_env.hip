@@ -24,7 +24,7 @@
 #include "dev_model.hpp"
 
 #ifndef FFE_WAVES_PER_SIMD
-#define FFE_WAVES_PER_SIMD 3  // register budget = 512 / this; picked by measurement
+#define FFE_WAVES_PER_SIMD 4  // register budget = 512 / this; picked by measurement: with the LDS tile under 10 KB, 16 waves fit a CU
 #endif
 
 namespace ffe {
@@ -62,8 +62,10 @@ struct alignas(16) Tile {
   float qvel[kMaxDof + 4];
   float xpos[kMaxLink][3];    // world (root-relative) link origin
   float xmat[kMaxLink][9];    // world link orientation
-  float cinert[kMaxLink][10]; // link spatial inertia about the com reference point
-  float crb[kMaxLink][10];    // composite (subtree) inertia
+  union {
+    float cinert[kMaxLink][10]; // link spatial inertia about the com reference point (until the subtree sums)
+    float crb[kMaxLink][10];    // composite (subtree) inertia (after them)
+  };
   float cdof[kMaxDof][6];     // dof axes, com-centred world frame
   union {
     float cdofd[kMaxDof][6];  // cdof_dot; dead once the per-link sums A1 are taken
@@ -553,6 +555,7 @@ __device__ void stage1(Ctx &c) {
     const I10 ci = is_link ? cin : z10;
     const I10 ctot = {wave_sum(ci.i0), wave_sum(ci.i1), wave_sum(ci.i2), wave_sum(ci.i3), wave_sum(ci.i4), wave_sum(ci.i5), wave_sum(ci.i6), wave_sum(ci.i7), wave_sum(ci.i8), wave_sum(ci.i9)};
     if (lane == 0) { fs = ftot; cr = ctot; }
+    SYNC();  // crb shares storage with cinert: every lane has finished reading the link inertias
     if (is_link) {
       st6(T.la[lane], fs);
       st10(T.crb[lane], cr);
