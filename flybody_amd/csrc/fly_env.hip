@@ -435,9 +435,7 @@ __device__ void stage1(Ctx &c) {
   STAMP(0);  // kinematics + com + cinert
   // ---- dof axes in the com-centred world frame (mj: mju_dofCom)
   S6 cd = zero6();
-  float qv = 0.f;
   if (is_dof) {
-    qv = T.qvel[lane];
     if (d_kind == 0) {
       int k = lane;  // translational root dofs are dofs 0..2
       cd = {0.f, 0.f, 0.f, k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f};
@@ -485,10 +483,10 @@ __device__ void stage1(Ctx &c) {
       int pl = M.l_parent[b];
       S6 cv = ld6(T.lb[pl]);
       for (int e = M.l_dofadr[b]; e < lane; e++) cv = cv + T.qvel[e] * ld6(T.cdof[e]);
-      cdd = cross_motion(cv, cd);
+      cdd = cross_motion(cv, ld6(T.cdof[lane]));
     } else if (d_kind == 1) {
       S6 cv = {0.f, 0.f, 0.f, T.qvel[0], T.qvel[1], T.qvel[2]};  // free joint: after the 3 translations only
-      cdd = cross_motion(cv, cd);
+      cdd = cross_motion(cv, ld6(T.cdof[lane]));
     }
     st6(T.cdofd[lane], cdd);
   }
@@ -511,13 +509,19 @@ __device__ void stage1(Ctx &c) {
       if (a != 0xff) cacc = cacc + ld6(T.la[a]);
     }
     if (!(c.flags & FFE_NO_GRAVITY)) { cacc.l0 -= M.gx; cacc.l1 -= M.gy; cacc.l2 -= M.gz; }
-    frc = mul_inert(cin, cacc) + cross_force(cvel, mul_inert(cin, cvel));
+    const I10 cin2 = ld10(T.cinert[lane]);
+    const S6 cvel2 = ld6(T.lb[lane]);
+    frc = mul_inert(cin2, cacc) + cross_force(cvel2, mul_inert(cin2, cvel2));
   }
   if (!(c.flags & FFE_NO_FLUID)) {
     // mj_passive fluid forces, evaluated in link coordinates: (w_b, v_b) = link angular velocity / origin velocity
-    const V3 off = xp - c.com;
-    const V3 w_w = ang(cvel);
-    const V3 w_b = mtv(xm, w_w), v_b = mtv(xm, lin(cvel) + cross(w_w, off));
+    const int ll = is_link ? lane : 0;
+    const V3 xp2 = {T.xpos[ll][0], T.xpos[ll][1], T.xpos[ll][2]};
+    const M3 xm2 = ldm(T.xmat[ll]);
+    const S6 cvel3 = ld6(T.lb[ll]);
+    const V3 off = xp2 - c.com;
+    const V3 w_w = ang(cvel3);
+    const V3 w_b = mtv(xm2, w_w), v_b = mtv(xm2, lin(cvel3) + cross(w_w, off));
     S6 wl = zero6();
     if (is_link) {
       const int kind = M.l_reckind[lane];
@@ -531,8 +535,8 @@ __device__ void stage1(Ctx &c) {
     wr = wave_sum6(wr);
     if (lane == 0) wl = wl + wr;
     if (is_link) {
-      const V3 f_w = mv(xm, lin(wl));
-      frc = frc - mk6(mv(xm, ang(wl)) + cross(off, f_w), f_w);
+      const V3 f_w = mv(xm2, lin(wl));
+      frc = frc - mk6(mv(xm2, ang(wl)) + cross(off, f_w), f_w);
     }
   }
   if (is_link) st6(T.lc[lane], frc);
@@ -542,7 +546,9 @@ __device__ void stage1(Ctx &c) {
   //          composite inertias (mj: mj_rne backward pass, mj_crb accumulation)
   {
     S6 fs = frc;
-    I10 cr = cin;
+    const I10 z10 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const I10 ci = is_link ? ld10(T.cinert[lane]) : z10;
+    I10 cr = ci;
     if (is_link && lane != 0) {
       for (int k = lane + 1; k < lane + l_sub; k++) {
         fs = fs + ld6(T.lc[k]);
@@ -551,8 +557,6 @@ __device__ void stage1(Ctx &c) {
     }
     // the root link's subtree is the whole tree: reduce across the wave instead of an 18-step serial sum
     const S6 ftot = wave_sum6(is_link ? frc : zero6());
-    const I10 z10 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const I10 ci = is_link ? cin : z10;
     const I10 ctot = {wave_sum(ci.i0), wave_sum(ci.i1), wave_sum(ci.i2), wave_sum(ci.i3), wave_sum(ci.i4), wave_sum(ci.i5), wave_sum(ci.i6), wave_sum(ci.i7), wave_sum(ci.i8), wave_sum(ci.i9)};
     if (lane == 0) { fs = ftot; cr = ctot; }
     SYNC();  // crb shares storage with cinert: every lane has finished reading the link inertias
@@ -564,14 +568,15 @@ __device__ void stage1(Ctx &c) {
   SYNC();
   // ---- joint space: bias projection, joint springs and dampers; crb * cdof
   if (is_dof) {
-    float bias = dot6(cd, ld6(T.la[d_link]));
+    const S6 cd2 = ld6(T.cdof[lane]);  // reloaded: keeping it in registers since the axes phase only raises pressure
+    float bias = dot6(cd2, ld6(T.la[d_link]));
     float f = -bias;
     if (d_kind == 2) {
       if (!(c.flags & FFE_NO_SPRING)) f -= M.d_stiff[lane] * (T.qpos[M.d_qadr[lane]] - M.d_sref[lane]);
     }
-    if (!(c.flags & FFE_NO_DAMPER)) f -= M.d_damp[lane] * qv;
+    if (!(c.flags & FFE_NO_DAMPER)) f -= M.d_damp[lane] * T.qvel[lane];
     c.f_smooth_nb = f;
-    st6(T.buf[lane], mul_inert(ld10(T.crb[d_link]), cd));
+    st6(T.buf[lane], mul_inert(ld10(T.crb[d_link]), cd2));
   }
   SYNC();
   // M(i,j) = cdof_j . (crb_i cdof_i) is formed directly into the factor's working copy (see factor)
