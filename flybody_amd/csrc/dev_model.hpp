@@ -85,10 +85,10 @@ class Blob {
 // ------------------------------------------------------------------------------------------------ device view
 // Pointers into the arena (device addresses once uploaded).  Lane-major tables: element (c, lane) at [c*64+lane].
 struct DevModel {
-  int nlink, nv, nq, nu, nM, ntri, nrootrec, nobsj, nwing, naction, maxdepth, nsub;
+  int nlink, nv, nq, nu, nM, nrootrec, nobsj, nwing, naction, nsub;
   float h, gx, gy, gz, total_mass;
   // per dof
-  const int FFE_GLOBAL *d_parent, *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id, *d_ndesc;  // d_act_id: [2][64]
+  const int FFE_GLOBAL *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id, *d_ndesc;  // d_act_id: [2][64]
   const unsigned int FFE_GLOBAL *pairtab;  // [256] elimination pairs (s | t << 8), sorted by t then s
   const float FFE_GLOBAL *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
       *d_act_coef;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
@@ -102,12 +102,10 @@ struct DevModel {
   const float FFE_GLOBAL *ell;
   // sparse-M index tables
   const unsigned char FFE_GLOBAL *m_row, *m_col;
-  const unsigned int FFE_GLOBAL *tri;
-  const int FFE_GLOBAL *tri_off;  // [nv+1]
   // actuators
-  const int FFE_GLOBAL *a_trn, *a_dof, *a_qadr, *a_cl, *a_fl, *a_action, *a_wrap_off, *w_qadr, *w_dof, *t_qadr, *t_dof;
+  const int FFE_GLOBAL *a_cl, *a_fl, *a_action, *t_qadr, *t_dof;
   const float FFE_GLOBAL *t_coef;
-  const float FFE_GLOBAL *a_gain, *a_b0, *a_b1, *a_b2, *a_clo, *a_chi, *a_flo, *a_fhi, *w_coef;
+  const float FFE_GLOBAL *a_gain, *a_b0, *a_b1, *a_b2, *a_clo, *a_chi, *a_flo, *a_fhi;
   // task bookkeeping
   const int FFE_GLOBAL *wing_dof, *wing_qadr, *wing_action, *obsj_qadr, *obsj_dof;
   int user_action;
@@ -167,7 +165,7 @@ struct HostModel {
       using P = std::remove_reference_t<decltype(p)>;
       p = (P)((size_t)base + (size_t)p);  // C-style: the member may carry a device address-space qualifier
     };
-    fix(dst.d_parent); fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
+    fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
     fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
     fix(dst.d_sref); fix(dst.d_lo); fix(dst.d_hi); fix(dst.d_margin); fix(dst.d_invw); fix(dst.d_K); fix(dst.d_B);
     fix(dst.d_solimp); fix(dst.d_act_coef);
@@ -175,11 +173,10 @@ struct HostModel {
     fix(dst.l_pos); fix(dst.l_quat); fix(dst.l_ipos); fix(dst.l_imat); fix(dst.l_inertia); fix(dst.l_mass);
     fix(dst.l_recpos); fix(dst.l_recmat); fix(dst.l_reccoef);
     fix(dst.rr_pos); fix(dst.rr_mat); fix(dst.rr_coef); fix(dst.ell);
-    fix(dst.m_row); fix(dst.m_col); fix(dst.tri); fix(dst.tri_off);
-    fix(dst.a_trn); fix(dst.a_dof); fix(dst.a_qadr); fix(dst.a_cl); fix(dst.a_fl); fix(dst.a_action);
-    fix(dst.a_wrap_off); fix(dst.w_qadr); fix(dst.w_dof); fix(dst.t_qadr); fix(dst.t_dof); fix(dst.t_coef);
+    fix(dst.m_row); fix(dst.m_col);
+    fix(dst.a_cl); fix(dst.a_fl); fix(dst.a_action); fix(dst.t_qadr); fix(dst.t_dof); fix(dst.t_coef);
     fix(dst.a_gain); fix(dst.a_b0); fix(dst.a_b1); fix(dst.a_b2); fix(dst.a_clo); fix(dst.a_chi); fix(dst.a_flo);
-    fix(dst.a_fhi); fix(dst.w_coef);
+    fix(dst.a_fhi);
     fix(dst.wing_dof); fix(dst.wing_qadr); fix(dst.wing_action); fix(dst.obsj_qadr); fix(dst.obsj_dof);
     fix(dst.qpos0);
   }
@@ -286,24 +283,7 @@ inline HostModel build_host_model(const Blob &b) {
   if ((maxdepth - 1) * maxdepth / 2 > 4 * kWave) throw std::runtime_error("dof chains too deep for the pair table");
   const int nM = static_cast<int>(m_row.size());
   if (nM > kMaxM) throw std::runtime_error("mass matrix exceeds kernel capacity");
-  V.nM = nM; V.maxdepth = maxdepth;
-  // elimination triples: for pivot k with ancestors a_1..a_n: M(a_s, a_t) -= M(k,a_s) M(k,a_t) / M(k,k), s <= t
-  std::vector<unsigned int> tri;
-  std::vector<int> tri_off(nv + 1, 0);
-  for (int k = 0; k < nv; k++) {
-    tri_off[k] = static_cast<int>(tri.size());
-    std::vector<int> anc;
-    for (int a = dofpar.i(k); a >= 0; a = dofpar.i(a)) anc.push_back(a);
-    int n = static_cast<int>(anc.size());
-    for (int s = 1; s <= n; s++)
-      for (int t = s; t <= n; t++) {
-        unsigned tgt = static_cast<unsigned>(d_madr[anc[s - 1]] + (t - s));
-        tri.push_back((tgt << 16) | (static_cast<unsigned>(s) << 8) | static_cast<unsigned>(t));
-      }
-  }
-  tri_off[nv] = static_cast<int>(tri.size());
-  V.ntri = static_cast<int>(tri.size());
-
+  V.nM = nM;
   // ---- links ---------------------------------------------------------------------------------------
   auto l_parent = lane_i(1, -1), l_dofadr = lane_i(1), l_dofnum = lane_i(1), l_sub = lane_i(1), l_reckind = lane_i(1),
        l_recell = lane_i(1);
@@ -466,7 +446,7 @@ inline HostModel build_host_model(const Blob &b) {
   if (site.f(4) != 1.0) throw std::runtime_error("sensor site must share the root body orientation");
 
   // ---- pack ------------------------------------------------------------------------------------------
-  set_off(V.d_parent, A.put(d_parent)); set_off(V.d_link, A.put(d_link));
+  set_off(V.d_link, A.put(d_link));
   set_off(V.d_madr, A.put(d_madr)); set_off(V.d_depth, A.put(d_depth));
   set_off(V.d_kind, A.put(d_kind)); set_off(V.d_qadr, A.put(d_qadr));
   set_off(V.d_limited, A.put(d_limited)); set_off(V.d_act_id, A.put(d_act_id));
@@ -490,18 +470,13 @@ inline HostModel build_host_model(const Blob &b) {
   set_off(V.rr_pos, A.put(rr_pos)); set_off(V.rr_mat, A.put(rr_mat));
   set_off(V.rr_coef, A.put(rr_coef)); set_off(V.ell, A.put(ell));
   set_off(V.m_row, A.put(m_row)); set_off(V.m_col, A.put(m_col));
-  set_off(V.tri, A.put(tri)); set_off(V.tri_off, A.put(tri_off));
-  set_off(V.a_trn, A.put(a_trn)); set_off(V.a_dof, A.put(a_dof));
-  set_off(V.a_qadr, A.put(a_qadr)); set_off(V.a_cl, A.put(a_cl));
+  set_off(V.a_cl, A.put(a_cl));
   set_off(V.a_fl, A.put(a_fl)); set_off(V.a_action, A.put(a_action));
-  set_off(V.a_wrap_off, A.put(a_wrap_off)); set_off(V.w_qadr, A.put(w_qadr));
-  set_off(V.w_dof, A.put(w_dof));
   set_off(V.t_qadr, A.put(t_qadr)); set_off(V.t_dof, A.put(t_dof)); set_off(V.t_coef, A.put(t_coef));
   set_off(V.a_gain, A.put(a_gain)); set_off(V.a_b0, A.put(a_b0));
   set_off(V.a_b1, A.put(a_b1)); set_off(V.a_b2, A.put(a_b2));
   set_off(V.a_clo, A.put(a_clo)); set_off(V.a_chi, A.put(a_chi));
   set_off(V.a_flo, A.put(a_flo)); set_off(V.a_fhi, A.put(a_fhi));
-  set_off(V.w_coef, A.put(w_coef));
   set_off(V.wing_dof, A.put(wing_dof)); set_off(V.wing_qadr, A.put(wing_qadr));
   set_off(V.wing_action, A.put(wing_action));
   set_off(V.obsj_qadr, A.put(obsj_qadr)); set_off(V.obsj_dof, A.put(obsj_dof));

@@ -790,9 +790,6 @@ __device__ float2 solve_both(Ctx &c, float rhs) {
   return make_float2(x0, x1);
 }
 
-struct StepOut {
-  V3 acc_sample;  // accelerometer reading of this substep (valid on every lane)
-};
 
 // Stage 2 = mj_fwdActuation, mj_fwdAcceleration, mj_fwdConstraint (joint limits), accelerometer, mj_Euler.
 // `ctrl_force` is the per-dof generalized actuator force, already assembled.
