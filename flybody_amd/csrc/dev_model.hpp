@@ -91,7 +91,7 @@ struct DevModel {
   const int FFE_GLOBAL *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id, *d_ndesc;  // d_act_id: [2][64]
   const unsigned int FFE_GLOBAL *pairtab;  // [256] elimination pairs (s | t << 8), sorted by t then s
   const float FFE_GLOBAL *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
-      *d_act_coef;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
+      *d_act_coef, *d_qpos0;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
   // per link
   const int FFE_GLOBAL *l_parent, *l_dofadr, *l_dofnum, *l_sub, *l_reckind, *l_recell;
   const unsigned int FFE_GLOBAL *l_anc;  // [2][64] ancestor links packed as bytes, nearest first, 0xff = none
@@ -168,7 +168,7 @@ struct HostModel {
     fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
     fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
     fix(dst.d_sref); fix(dst.d_lo); fix(dst.d_hi); fix(dst.d_margin); fix(dst.d_invw); fix(dst.d_K); fix(dst.d_B);
-    fix(dst.d_solimp); fix(dst.d_act_coef);
+    fix(dst.d_solimp); fix(dst.d_act_coef); fix(dst.d_qpos0);
     fix(dst.l_anc); fix(dst.l_parent); fix(dst.l_dofadr); fix(dst.l_dofnum); fix(dst.l_sub); fix(dst.l_reckind); fix(dst.l_recell);
     fix(dst.l_pos); fix(dst.l_quat); fix(dst.l_ipos); fix(dst.l_imat); fix(dst.l_inertia); fix(dst.l_mass);
     fix(dst.l_recpos); fix(dst.l_recmat); fix(dst.l_reccoef);
@@ -222,7 +222,7 @@ inline HostModel build_host_model(const Blob &b) {
        d_qadr = lane_i(1), d_limited = lane_i(1), d_act_id = lane_i(2, -1);
   auto d_axis = lane_f(3), d_arm = lane_f(1), d_damp = lane_f(1), d_stiff = lane_f(1), d_sref = lane_f(1),
        d_lo = lane_f(1), d_hi = lane_f(1), d_margin = lane_f(1), d_invw = lane_f(1), d_K = lane_f(1), d_B = lane_f(1),
-       d_solimp = lane_f(5), d_act_coef = lane_f(2);
+       d_solimp = lane_f(5), d_act_coef = lane_f(2), d_qpos0 = lane_f(1);
   std::vector<unsigned char> m_row, m_col;
   int maxdepth = 0;
   for (int d = 0; d < nv; d++) {
@@ -238,6 +238,7 @@ inline HostModel build_host_model(const Blob &b) {
     d_damp[d] = static_cast<float>(b.get("dof_damping").f(d));
     d_invw[d] = static_cast<float>(b.get("dof_invweight0").f(d));
     if (jt == 3) {
+      d_qpos0[d] = static_cast<float>(b.get("qpos0").f(jnt_qadr.i(j)));
       d_stiff[d] = static_cast<float>(b.get("jnt_stiffness").f(j));
       d_sref[d] = static_cast<float>(b.get("qpos_spring").f(jnt_qadr.i(j)));
       d_limited[d] = b.get("jnt_limited").i(j);
@@ -294,6 +295,7 @@ inline HostModel build_host_model(const Blob &b) {
     l_parent[k] = lparent.i(k);
     l_dofadr[k] = b.get("link_dofadr").i(k);
     l_dofnum[k] = b.get("link_dofnum").i(k);
+    if (k > 0 && l_dofnum[k] > 3) throw std::runtime_error("a non-root link carries more than 3 hinges");
     l_sub[k] = b.get("link_subtree").i(k);
     for (int c = 0; c < 3; c++) l_pos[c * kLanePad + k] = static_cast<float>(b.get("link_pos").f(3 * k + c));
     for (int c = 0; c < 4; c++) l_quat[c * kLanePad + k] = static_cast<float>(b.get("link_quat").f(4 * k + c));
@@ -457,7 +459,7 @@ inline HostModel build_host_model(const Blob &b) {
   set_off(V.d_hi, A.put(d_hi)); set_off(V.d_margin, A.put(d_margin));
   set_off(V.d_invw, A.put(d_invw)); set_off(V.d_K, A.put(d_K));
   set_off(V.d_B, A.put(d_B)); set_off(V.d_solimp, A.put(d_solimp));
-  set_off(V.d_act_coef, A.put(d_act_coef));
+  set_off(V.d_act_coef, A.put(d_act_coef)); set_off(V.d_qpos0, A.put(d_qpos0));
   set_off(V.l_anc, A.put(l_anc));
   set_off(V.l_parent, A.put(l_parent)); set_off(V.l_dofadr, A.put(l_dofadr));
   set_off(V.l_dofnum, A.put(l_dofnum)); set_off(V.l_sub, A.put(l_sub));

@@ -369,13 +369,23 @@ __device__ void stage1(Ctx &c) {
       p = {0.f, 0.f, 0.f};
     } else {
       Q4 qr = {1.f, 0.f, 0.f, 0.f};
-      for (int j = l_dofnum - 1; j >= 0; j--) {
-        int d = l_dofadr + j;
-        V3 ax = ldv_lane(M.d_axis, d);
-        int qa = M.d_qadr[d];
-        V3 bax = qrot(qconj(qr), ax);
-        T.cdof[d][0] = bax.x; T.cdof[d][1] = bax.y; T.cdof[d][2] = bax.z;
-        qr = qmul(axis_angle(ax, T.qpos[qa] - M.qpos0[qa]), qr);
+      // a link carries at most 3 hinges: fetch axes / addresses / reference angles of all of them first
+      V3 jax[3];
+      int jqa[3];
+      float jq0[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int d = l_dofadr + (j < l_dofnum ? j : 0);
+        jax[j] = ldv_lane(M.d_axis, d); jqa[j] = M.d_qadr[d]; jq0[j] = M.d_qpos0[d];
+      }
+#pragma unroll
+      for (int j = 2; j >= 0; j--) {
+        if (j < l_dofnum) {
+          const int d = l_dofadr + j;
+          const V3 bax = qrot(qconj(qr), jax[j]);
+          T.cdof[d][0] = bax.x; T.cdof[d][1] = bax.y; T.cdof[d][2] = bax.z;
+          qr = qmul(axis_angle(jax[j], T.qpos[jqa[j]] - jq0[j]), qr);
+        }
       }
       q = qmul(Q4{M.l_quat[lane], M.l_quat[kLanePad + lane], M.l_quat[2 * kLanePad + lane], M.l_quat[3 * kLanePad + lane]}, qr);
       p = ldv_lane(M.l_pos, lane);
@@ -920,17 +930,24 @@ __device__ float actuation(Ctx &c, const float *ctrl_lds) {
   const int lane = c.lane;
   if (c.flags & FFE_NO_ACTUATION) return 0.f;
   if (lane < M.nu) {
+    // phase 1: every table read of this actuator is issued before anything waits (independent addresses)
+    int tq[kMaxWrap], td[kMaxWrap];
+    float tc[kMaxWrap];
+#pragma unroll
+    for (int w = 0; w < kMaxWrap; w++) {  // zero-padded transmission terms: joint actuators have one, fixed tendons several
+      tq[w] = M.t_qadr[w * kMaxAct + lane]; td[w] = M.t_dof[w * kMaxAct + lane]; tc[w] = M.t_coef[w * kMaxAct + lane];
+    }
+    const int cl = M.a_cl[lane], fl = M.a_fl[lane];
+    const float clo = M.a_clo[lane], chi = M.a_chi[lane], gain = M.a_gain[lane], b0 = M.a_b0[lane], b1 = M.a_b1[lane], b2 = M.a_b2[lane],
+                flo = M.a_flo[lane], fhi = M.a_fhi[lane];
+    // phase 2
     float ctrl = ctrl_lds[lane];
-    if (M.a_cl[lane]) ctrl = fminf(fmaxf(ctrl, M.a_clo[lane]), M.a_chi[lane]);
+    ctrl = cl ? fminf(fmaxf(ctrl, clo), chi) : ctrl;
     float len = 0.f, vel = 0.f;
 #pragma unroll
-    for (int w = 0; w < kMaxWrap; w++) {  // zero-padded transmission terms: independent loads, no data-dependent loop
-      const float cf = M.t_coef[w * kMaxAct + lane];
-      len += cf * T.qpos[M.t_qadr[w * kMaxAct + lane]];
-      vel += cf * T.qvel[M.t_dof[w * kMaxAct + lane]];
-    }
-    float force = M.a_gain[lane] * ctrl + M.a_b0[lane] + M.a_b1[lane] * len + M.a_b2[lane] * vel;
-    if (M.a_fl[lane]) force = fminf(fmaxf(force, M.a_flo[lane]), M.a_fhi[lane]);
+    for (int w = 0; w < kMaxWrap; w++) { len += tc[w] * T.qpos[tq[w]]; vel += tc[w] * T.qvel[td[w]]; }
+    float force = gain * ctrl + b0 + b1 * len + b2 * vel;
+    force = fl ? fminf(fmaxf(force, flo), fhi) : force;
     T.frc[lane] = force;
   }
   SYNC();
