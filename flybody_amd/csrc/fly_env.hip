@@ -304,6 +304,7 @@ struct Ctx {
   float f_smooth_nb;  // passive(spring+damper) - bias + fluid per dof lane (actuation is added in stage 2)
   float qacc;         // constrained acceleration (mj: d->qacc)
   float dinv[2];      // 1 / D of this lane's dof for the two resident factorisations
+  unsigned la_pack;   // this lane's row start | depth << 10 | descendant count << 16 (read by every factor / solve)
 #ifdef FFE_STAMPS
   unsigned long long st_t0, st_acc[16];
 #endif
@@ -609,7 +610,7 @@ __device__ void factor(Ctx &c, float add0, float add1) {
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
-  const int d_madr = M.d_madr[lane], d_depth = M.d_depth[lane];
+  const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f;
   unsigned pr[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) pr[r] = M.pairtab[lane + r * kWave];
@@ -694,7 +695,7 @@ __device__ float solve(Ctx &c, float rhs) {
   Tile &T = c.T;
   const int lane = c.lane;
   const int nv = M.nv;
-  const int d_madr = M.d_madr[lane], d_depth = M.d_depth[lane], d_ndesc = M.d_ndesc[lane];
+  const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
   const bool is_dof = lane < nv;
   const float dinv = c.dinv[COMP];
   const float *LDc = reinterpret_cast<const float *>(T.LD) + COMP;  // entry e of this factor sits at LDc[2 e]
@@ -756,7 +757,7 @@ __device__ float2 solve_both(Ctx &c, float rhs) {
   const int lane = c.lane;
   const int nv = M.nv;
   const bool is_dof = lane < nv;
-  const int d_madr = M.d_madr[lane], d_depth = M.d_depth[lane], d_ndesc = M.d_ndesc[lane];
+  const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
   const float di0 = c.dinv[0], di1 = c.dinv[1];
   if (c.flags & DBG_SKIP_SOLVE) return is_dof ? make_float2(rhs * di0, rhs * di1) : make_float2(0.f, 0.f);
   STAMP(6);
@@ -1034,6 +1035,7 @@ __device__ void write_obs(Ctx &c, const TaskDev FFE_CONST &K, float *obs, V3 s_a
 __device__ __forceinline__ void load_lane_consts(Ctx &c) {
   const DevModel FFE_CONST &M = *c.Mp;
   c.dinv[0] = c.dinv[1] = 0.f;
+  c.la_pack = (unsigned)M.d_madr[c.lane] | ((unsigned)M.d_depth[c.lane] << 10) | ((unsigned)M.d_ndesc[c.lane] << 16);
   for (int e = c.lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
 }
 
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   if (env >= batch) return;
   const int lane = threadIdx.x;
   EnvState &S = states[env];
-  Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}};
+  Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}, 0u};
 #ifdef FFE_STAMPS
   c.st_t0 = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < 16; k++) c.st_acc[k] = 0;
