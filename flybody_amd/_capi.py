@@ -42,10 +42,17 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("FLYBODY_ENV_LIB"):
+        try:  # a fresh checkout: compile in-tree once (hipcc cross-compiles gfx950 without a GPU)
+            from . import build as _build
+
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError(
+                f"{LIB_PATH} is missing and could not be built ({e}); run `python -m flybody_amd.build` (hipcc, gfx950). "
+                "flybody_amd has no CPU fallback.") from e
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m flybody_amd.build` (hipcc, gfx950). "
-            "flybody_amd has no CPU fallback.")
+        raise RuntimeError(f"{LIB_PATH} is missing; flybody_amd has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     vp, fp, ip, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
     L.ffe_create_flight.restype = C.c_int
