@@ -63,7 +63,7 @@ def read_blob(path: str) -> dict:
     return out
 
 
-def model_tensors(m, L) -> dict:
+def model_tensors(m, L=None) -> dict:
     """Flatten a `CompiledModel` + `LinkModel` (+ the walker's action/observation bookkeeping)."""
     w = m.walker
     nu = m.nu
@@ -114,6 +114,26 @@ def model_tensors(m, L) -> dict:
         "user_action": np.array(w["action_indices"]["user"], dtype=np.int32),
         "wing_jnt": np.array(wing, dtype=np.int32),
         "obs_jnt": np.array(obs_j, dtype=np.int32),
+    }
+    if len(m.geom_bodyid):  # contact-capable models (walk_on_ball)
+        sid = {n: k for k, n in enumerate(m.sites_name)}
+        app = [sid[n] for n in ("claw_T1_left", "claw_T1_right", "claw_T2_left", "claw_T2_right", "claw_T3_left",
+                                "claw_T3_right", "head") if n in sid]  # `fruitfly.py:421-447`
+        t.update({
+            "geom_bodyid": m.geom_bodyid, "geom_type": m.geom_type, "geom_size": m.geom_size, "geom_pos": m.geom_pos,
+            "geom_quat": m.geom_quat, "geom_condim": m.geom_condim, "geom_friction": m.geom_friction,
+            "geom_margin": m.geom_margin, "geom_gap": m.geom_gap, "geom_solref": m.geom_solref,
+            "geom_solimp": m.geom_solimp, "geom_solmix": m.geom_solmix, "geom_priority": m.geom_priority,
+            "geom_contype": m.geom_contype, "geom_conaffinity": m.geom_conaffinity,
+            "exclude_pairs": m.exclude_pairs, "body_weldid": m.body_weldid, "body_invweight0": m.body_invweight0,
+            "sites_bodyid": m.sites_bodyid, "sites_pos": m.sites_pos, "sites_quat": m.sites_quat,
+            "sites_type": m.sites_type, "sites_size": m.sites_size,
+            "touch_site": m.touch_site, "force_site": m.force_site, "appendage_site": np.array(app, dtype=np.int32),
+            "solver_opt": np.array([m.cone_elliptic, m.noslip_iterations, m.impratio], dtype=np.float64),
+        })
+    if L is None:
+        return t
+    t.update({
         # welded links
         "link_body": L.link_body, "link_parent": L.link_parent, "link_pos": L.link_pos,
         "link_quat": L.link_quat, "link_mass": L.link_mass, "link_ipos": L.link_ipos,
@@ -123,7 +143,7 @@ def model_tensors(m, L) -> dict:
         "fbox_link": L.fbox_link, "fbox_pos": L.fbox_pos, "fbox_mat": L.fbox_mat, "fbox_box": L.fbox_box,
         "fell_link": L.fell_link, "fell_pos": L.fell_pos, "fell_mat": L.fell_mat,
         "fell_size": L.fell_size, "fell_coef": L.fell_coef,
-    }
+    })
     return t
 
 

@@ -327,6 +327,39 @@ class CompiledModel:
     site_bodyid: int = 0
     site_pos: np.ndarray = None
     site_quat: np.ndarray = None
+    # collision geoms (contype|conaffinity != 0 only), MuJoCo type codes
+    geom_name: list = field(default_factory=list)
+    geom_bodyid: np.ndarray = None
+    geom_type: np.ndarray = None
+    geom_size: np.ndarray = None
+    geom_pos: np.ndarray = None
+    geom_quat: np.ndarray = None
+    geom_condim: np.ndarray = None
+    geom_friction: np.ndarray = None
+    geom_margin: np.ndarray = None
+    geom_gap: np.ndarray = None
+    geom_solref: np.ndarray = None
+    geom_solimp: np.ndarray = None
+    geom_solmix: np.ndarray = None
+    geom_priority: np.ndarray = None
+    geom_contype: np.ndarray = None
+    geom_conaffinity: np.ndarray = None
+    exclude_pairs: np.ndarray = None  # (n, 2) body ids from <contact><exclude>
+    body_weldid: np.ndarray = None
+    body_invweight0: np.ndarray = None  # (nbody, 2): translational, rotational
+    # named sites (all of them) and the sensors that refer to them
+    sites_name: list = field(default_factory=list)
+    sites_bodyid: np.ndarray = None
+    sites_pos: np.ndarray = None
+    sites_quat: np.ndarray = None
+    sites_type: np.ndarray = None
+    sites_size: np.ndarray = None
+    touch_site: np.ndarray = None
+    force_site: np.ndarray = None
+    # solver options
+    cone_elliptic: int = 0
+    noslip_iterations: int = 0
+    impratio: float = 1.0
     # bookkeeping from the walker
     walker: dict = field(default_factory=dict)
     notes: dict = field(default_factory=dict)
@@ -560,11 +593,12 @@ def compile_model(doc: Document, mesh_dir: str, fallback_mesh_dir: str, timestep
         m.body_parentid[i] = parent_of[i]
         m.body_pos[i] = b.num("pos", np.zeros(3))
         m.body_quat[i] = Q.normalize(b.num("quat", np.array([1.0, 0, 0, 0])))
-    if free_root:
-        # dm_control attaches the walker under a frame body at the spawn site that carries the
-        # free joint (`tasks/base.py:130-133`); thorax sits at that frame's origin, so giving the
-        # thorax the free joint with qpos0 = spawn pose is the same model.
-        m.body_pos[1] = np.asarray(spawn_pos, dtype=np.float64)
+    # dm_control attaches the walker under a frame body at the spawn site (`tasks/base.py:130-133`);
+    # thorax sits at that frame's origin.  With a free joint on the frame, giving the thorax the free
+    # joint with qpos0 = spawn pose is the same model; without one (`walk_on_ball.py:30`) the thorax is
+    # simply fixed to the world at the spawn position.
+    root_idx = m.body_name.index("thorax")
+    m.body_pos[root_idx] = np.asarray(spawn_pos, dtype=np.float64)
 
     # ---- geoms -> body inertials ---------------------------------------------------------------
     geoms_of = {i: [c for c in b.children if c.tag == "geom"] for i, b in enumerate(bodies, start=1)}
@@ -642,7 +676,7 @@ def compile_model(doc: Document, mesh_dir: str, fallback_mesh_dir: str, timestep
     last_dof_of_body = np.full(nb, -1, dtype=np.int32)
     for i, b in enumerate(bodies, start=1):
         joints = [c for c in b.children if c.tag in ("joint", "freejoint")]
-        if i == 1 and free_root and not any(c.tag == "freejoint" or c.attrib.get("type") == "free" for c in joints):
+        if i == root_idx and free_root and not any(c.tag == "freejoint" or c.attrib.get("type") == "free" for c in joints):
             joints = [Element("freejoint", {"name": "free"}, b)] + joints
         pid = m.body_parentid[i]
         inherit = last_dof_of_body[pid] if pid >= 0 else -1
@@ -673,6 +707,21 @@ def compile_model(doc: Document, mesh_dir: str, fallback_mesh_dir: str, timestep
                 qspring.extend(list(m.body_pos[i]) + list(m.body_quat[i]))
                 ndof = 6
                 damp, arm = 0.0, 0.0
+            elif jtype == "ball":
+                jt.append(JNT_BALL)
+                jax.append(np.array([0.0, 0, 1]))
+                jlim.append(0)
+                jrng.append(np.zeros(2))
+                jst.append(float(_f(a.get("stiffness", "0"))[0]))
+                jmar.append(0.0)
+                jsr.append(np.array([0.02, 1.0]))
+                jsi.append(np.array([0.9, 0.95, 0.001, 0.5, 2.0]))
+                jspringdamper.append(np.zeros(2))
+                qpos0.extend([1.0, 0, 0, 0])
+                qspring.extend([1.0, 0, 0, 0])
+                ndof = 3
+                damp = float(_f(a.get("damping", "0"))[0])
+                arm = float(_f(a.get("armature", "0"))[0])
             elif jtype == "hinge":
                 jt.append(JNT_HINGE)
                 ax = _f(a["axis"]) if "axis" in a else np.array([0.0, 0, 1])
@@ -744,6 +793,9 @@ def compile_model(doc: Document, mesh_dir: str, fallback_mesh_dir: str, timestep
             d = m.jnt_dofadr[j]
             m.dof_invweight0[d : d + 3] = np.mean(np.diag(Minv)[d : d + 3])
             m.dof_invweight0[d + 3 : d + 6] = np.mean(np.diag(Minv)[d + 3 : d + 6])
+        elif m.jnt_type[j] == JNT_BALL:
+            d = m.jnt_dofadr[j]
+            m.dof_invweight0[d : d + 3] = np.mean(np.diag(Minv)[d : d + 3])
 
     # ---- fluid ---------------------------------------------------------------------------------
     m.body_fluid_kind = np.zeros(nb, dtype=np.int32)
@@ -854,6 +906,102 @@ def compile_model(doc: Document, mesh_dir: str, fallback_mesh_dir: str, timestep
     m.site_bodyid = m.body_name.index(site.parent.name)
     m.site_pos = site.num("pos", np.zeros(3))
     m.site_quat = Q.normalize(site.num("quat", np.array([1.0, 0, 0, 0])))
+
+    # ---- solver options ---------------------------------------------------------------------------------
+    m.cone_elliptic = int(opt.get("cone", "pyramidal") == "elliptic")
+    m.noslip_iterations = int(opt.get("noslip_iterations", 0))
+    m.impratio = float(opt.get("impratio", 1.0))
+
+    # ---- collision geoms, contact excludes, weld ids ------------------------------------------------------
+    GEOM_CODE = {"plane": 0, "hfield": 1, "sphere": 2, "capsule": 3, "ellipsoid": 4, "cylinder": 5, "box": 6, "mesh": 7}
+    gb, gt, gs, gp, gq, gcd, gfr, gma, gga, gsr, gsi, gmx, gpr, gct, gca = ([] for _ in range(15))
+    for i in range(1, nb):
+        for g in geoms_of[i]:
+            a = doc.resolved(g)
+            ct, ca = int(a.get("contype", 1)), int(a.get("conaffinity", 1))
+            if ct == 0 and ca == 0:
+                continue
+            gtype = a.get("type") or ("mesh" if "mesh" in a else "sphere")
+            pos, quat, size = _geom_frame(a)
+            m.geom_name.append(g.name)
+            gb.append(i)
+            gt.append(GEOM_CODE[gtype])
+            gs.append(size)
+            gp.append(pos)
+            gq.append(quat)
+            gcd.append(int(a.get("condim", 3)))
+            fr = _f(a.get("friction", "1 0.005 0.0001"))
+            gfr.append(np.hstack((fr, [1.0, 0.005, 0.0001][len(fr):])))
+            gma.append(float(_f(a.get("margin", "0"))[0]))
+            gga.append(float(_f(a.get("gap", "0"))[0]))
+            gsr.append(_f(a.get("solref", "0.02 1")))
+            si = _f(a.get("solimp", "0.9 0.95 0.001 0.5 2"))
+            gsi.append(np.hstack((si, [0.9, 0.95, 0.001, 0.5, 2.0][len(si):])))
+            gmx.append(float(_f(a.get("solmix", "1"))[0]))
+            gpr.append(int(a.get("priority", 0)))
+            gct.append(ct)
+            gca.append(ca)
+    m.geom_bodyid = np.array(gb, dtype=np.int32)
+    m.geom_type = np.array(gt, dtype=np.int32)
+    m.geom_size = np.array(gs).reshape(-1, 3)
+    m.geom_pos = np.array(gp).reshape(-1, 3)
+    m.geom_quat = np.array(gq).reshape(-1, 4)
+    m.geom_condim = np.array(gcd, dtype=np.int32)
+    m.geom_friction = np.array(gfr).reshape(-1, 3)
+    m.geom_margin = np.array(gma)
+    m.geom_gap = np.array(gga)
+    m.geom_solref = np.array(gsr).reshape(-1, 2)
+    m.geom_solimp = np.array(gsi).reshape(-1, 5)
+    m.geom_solmix = np.array(gmx)
+    m.geom_priority = np.array(gpr, dtype=np.int32)
+    m.geom_contype = np.array(gct, dtype=np.int32)
+    m.geom_conaffinity = np.array(gca, dtype=np.int32)
+    ex = []
+    csec = doc.section("contact")
+    for e in csec.children if csec is not None else []:
+        if e.tag == "exclude":
+            ex.append([bname2id[e.attrib["body1"]], bname2id[e.attrib["body2"]]])
+    m.exclude_pairs = np.array(ex, dtype=np.int32).reshape(-1, 2)
+    m.body_weldid = np.zeros(nb, dtype=np.int32)
+    for i in range(1, nb):
+        m.body_weldid[i] = i if m.body_jntnum[i] > 0 else m.body_weldid[m.body_parentid[i]]
+
+    # ---- body inverse weights at qpos0 (mj: setM0/`mj_setConst`: mean diagonal of J M^-1 J' per body) ----
+    from .pyref import body_jacobians
+
+    m.body_invweight0 = np.zeros((nb, 2))
+    if len(m.geom_bodyid):
+        jacp, jacr = body_jacobians(m, m.qpos0)
+        for i in range(1, nb):
+            if m.body_weldid[i] == 0:
+                continue
+            Ap = jacp[i] @ Minv @ jacp[i].T
+            Ar = jacr[i] @ Minv @ jacr[i].T
+            m.body_invweight0[i] = [np.trace(Ap) / 3, np.trace(Ar) / 3]
+
+    # ---- all sites, touch / force sensors -------------------------------------------------------------------
+    SITE_CODE = {"sphere": 2, "capsule": 3, "ellipsoid": 4, "cylinder": 5, "box": 6}
+    sb, sp, sq, st, ss = [], [], [], [], []
+    for i, b in enumerate(bodies, start=1):
+        for c in b.children:
+            if c.tag != "site":
+                continue
+            a = doc.resolved(c)
+            pos, quat, size = _geom_frame(a)
+            m.sites_name.append(c.name)
+            sb.append(i)
+            sp.append(pos)
+            sq.append(quat)
+            st.append(SITE_CODE[a.get("type", "sphere")])
+            ss.append(size)
+    m.sites_bodyid = np.array(sb, dtype=np.int32)
+    m.sites_pos = np.array(sp).reshape(-1, 3)
+    m.sites_quat = np.array(sq).reshape(-1, 4)
+    m.sites_type = np.array(st, dtype=np.int32)
+    m.sites_size = np.array(ss).reshape(-1, 3)
+    sname2id = {n: k for k, n in enumerate(m.sites_name)}
+    m.touch_site = np.array([sname2id[e.attrib["site"]] for e in doc.find_all("sensor") if e.tag == "touch"], dtype=np.int32)
+    m.force_site = np.array([sname2id[e.attrib["site"]] for e in doc.find_all("sensor") if e.tag == "force"], dtype=np.int32)
     return m
 
 
@@ -1016,3 +1164,46 @@ def build_flight_model(assets_dir: str = REFERENCE_ASSETS, msh_dir: str = REFERE
     m = compile_model(doc, assets_dir, msh_dir, timestep=5e-5, mesh_rule=mesh_rule)
     m.walker = walker
     return m, weld(m)
+
+
+def apply_walking_edits(doc: Document) -> None:
+    """`tasks/base.py:159-161` (mass bounds) are no-ops here; `Walking.__init__` only touches the arena's
+    ground geoms (`tasks/base.py:353-357`), which `build_ball_model` writes directly."""
+
+
+def apply_walk_on_ball_edits(doc: Document, claw_friction=1.0) -> None:
+    """`tasks/walk_on_ball.py:30-45`: thorax-children contact excludes and the claw friction override."""
+    csec = doc.section("contact")
+    thorax = doc.find("body", "thorax")
+    for child in thorax.children:
+        if child.tag == "body":
+            csec.add(Element("exclude", {"name": f"thorax_{child.name}", "body1": "thorax", "body2": child.name}))
+    if claw_friction is not None:
+        doc.classes["adhesion-collision"].own.setdefault("geom", {})["friction"] = str(claw_friction)
+
+
+def build_ball_model(assets_dir: str = REFERENCE_ASSETS, msh_dir: str = REFERENCE_MSH, mesh_rule: str = "legacy",
+                     ball_pos=(-0.05, 0.0, -0.419), ball_radius=0.454, ball_density=0.0025,
+                     joint_filter=0.01, adhesion_filter=0.007, claw_friction=1.0) -> CompiledModel:
+    """The model `fly_envs.walk_on_ball` compiles (`fly_envs.py:125-157`): legs on, wings / mouth / antennae
+    passive, thorax fixed to the world, a free-spinning ball under the legs (`tasks/arenas/ball.py:61-69`),
+    filtered position actuators, 2e-4 s physics step (`tasks/constants.py:16-17`)."""
+    doc = Document(os.path.join(assets_dir, "fruitfly.xml"))
+    fj = doc.find("freejoint", "free")
+    if fj is not None:
+        fj.remove()
+    wopt = WalkerOptions(use_legs=True, use_wings=False, use_mouth=False, use_antennae=False,
+                         joint_filter=joint_filter, adhesion_filter=adhesion_filter, num_user_actions=0)
+    walker = apply_walker_edits(doc, wopt)
+    apply_walk_on_ball_edits(doc, claw_friction)
+    # the arena's ball precedes the attached walker in the world body (`tasks/arenas/ball.py:61`, then
+    # `tasks/base.py:130`); ground-geom contact parameters from `tasks/base.py:353-357`
+    ball = Element("body", {"name": "ball", "pos": np.asarray(ball_pos, dtype=np.float64)}, doc.worldbody)
+    ball.add(Element("geom", {"name": "ball_geom", "type": "sphere", "size": np.array([ball_radius, 0.0, 0.0]),
+                              "density": str(ball_density), "friction": "0.5 0.005 0.0001", "solref": "0.001 1",
+                              "solimp": "0.95 0.99 0.01", "contype": "1", "conaffinity": "1", "condim": "3"}))
+    ball.add(Element("joint", {"name": "ball", "type": "ball"}))
+    doc.worldbody.children.insert(0, ball)
+    m = compile_model(doc, assets_dir, msh_dir, timestep=2e-4, mesh_rule=mesh_rule, free_root=False)
+    m.walker = walker
+    return m

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import quat as Q
 
-JNT_FREE, JNT_HINGE = 0, 3
+JNT_FREE, JNT_BALL, JNT_HINGE = 0, 1, 3
 
 
 def kinematics(m, qpos):
@@ -39,8 +39,12 @@ def kinematics(m, qpos):
                     raise NotImplementedError
                 xanchor[j] = Q.rot(m.jnt_pos[j], quat) + pos
                 xaxis[j] = Q.rot(m.jnt_axis[j], quat)
-                ang = qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]]
-                quat = Q.mul(quat, Q.axis_angle(m.jnt_axis[j], ang))
+                if m.jnt_type[j] == JNT_BALL:
+                    qa = m.jnt_qposadr[j]
+                    quat = Q.mul(quat, Q.normalize(qpos[qa : qa + 4]))
+                else:
+                    ang = qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]]
+                    quat = Q.mul(quat, Q.axis_angle(m.jnt_axis[j], ang))
                 pos = xanchor[j] - Q.rot(m.jnt_pos[j], quat)
             xpos[i], xquat[i] = pos, Q.normalize(quat)
     xipos = np.array([xpos[i] + Q.rot(m.body_ipos[i], xquat[i]) for i in range(nb)])
@@ -67,6 +71,7 @@ def mass_matrix(m, qpos):
     com, _ = subtree_com(m, k)
     c0 = com[1]
     nb, nv = m.nbody, m.nv
+    cdof = _cdof(m, k, c0)
     # 6x6 spatial inertia (angular first) of every body about c0, world axes
     I6 = np.zeros((nb, 6, 6))
     for i in range(1, nb):
@@ -81,7 +86,20 @@ def mass_matrix(m, qpos):
         I6[i, 3:, 3:] = mass * np.eye(3)
     for i in range(nb - 1, 0, -1):
         I6[m.body_parentid[i]] += I6[i]
-    cdof = np.zeros((nv, 6))
+    M = np.zeros((nv, nv))
+    for i in range(nv):
+        f = I6[m.dof_bodyid[i]] @ cdof[i]
+        j = i
+        while j >= 0:
+            M[i, j] = M[j, i] = cdof[j] @ f
+            j = m.dof_parentid[j]
+        M[i, i] += m.dof_armature[i]
+    return M
+
+
+def _cdof(m, k, c0):
+    """Motion axes of every dof (angular; linear at point c0), world frame."""
+    cdof = np.zeros((m.nv, 6))
     for j in range(m.njnt):
         b = m.jnt_bodyid[j]
         d = m.jnt_dofadr[j]
@@ -94,16 +112,37 @@ def mass_matrix(m, qpos):
                 ax = R[:, a]
                 cdof[d + 3 + a, :3] = ax
                 cdof[d + 3 + a, 3:] = np.cross(ax, off)
+        elif m.jnt_type[j] == JNT_BALL:
+            R = Q.to_mat(k["xquat"][b])
+            for a in range(3):
+                ax = R[:, a]
+                cdof[d + a, :3] = ax
+                cdof[d + a, 3:] = np.cross(ax, off)
         else:
             ax = k["xaxis"][j]
             cdof[d, :3] = ax
             cdof[d, 3:] = np.cross(ax, off)
-    M = np.zeros((nv, nv))
-    for i in range(nv):
-        f = I6[m.dof_bodyid[i]] @ cdof[i]
-        j = i
-        while j >= 0:
-            M[i, j] = M[j, i] = cdof[j] @ f
-            j = m.dof_parentid[j]
-        M[i, i] += m.dof_armature[i]
-    return M
+    return cdof
+
+
+def body_jacobians(m, qpos):
+    """Translational (at the body CoM) and rotational Jacobians of every body: (nbody, 3, nv) each."""
+    k = kinematics(m, qpos)
+    c0 = np.zeros(3)
+    cdof = _cdof(m, k, c0)
+    nb, nv = m.nbody, m.nv
+    jacp = np.zeros((nb, 3, nv))
+    jacr = np.zeros((nb, 3, nv))
+    for i in range(1, nb):
+        b = i
+        while b > 0 and m.body_dofnum[b] == 0:
+            b = m.body_parentid[b]
+        if b <= 0:
+            continue
+        d = m.body_dofadr[b] + m.body_dofnum[b] - 1
+        while d >= 0:
+            w, v0 = cdof[d, :3], cdof[d, 3:]
+            jacr[i][:, d] = w
+            jacp[i][:, d] = v0 + np.cross(w, k["xipos"][i] - c0)
+            d = m.dof_parentid[d]
+    return jacp, jacr

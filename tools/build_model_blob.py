@@ -12,7 +12,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 from flybody_amd.model.blob import model_tensors, write_blob
-from flybody_amd.model.compiler import build_flight_model
+from flybody_amd.model.compiler import build_ball_model, build_flight_model
 
 OUT = os.path.join(os.path.dirname(__file__), "..", "flybody_amd", "assets")
 
@@ -33,6 +33,18 @@ def main():
     with open(os.path.join(OUT, "fly_flight.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote", OUT, "nbody", m.nbody, "nv", m.nv, "nu", m.nu)
+    b = build_ball_model()
+    write_blob(os.path.join(OUT, "fly_ball.ffmb"), model_tensors(b))
+    meta = {
+        "body_name": b.body_name, "jnt_name": b.jnt_name, "act_name": b.act_name, "ten_name": b.ten_name,
+        "geom_name": b.geom_name, "site_name": b.sites_name,
+        "observable_joints": b.walker["observable_joints"],
+        "action_names": [b.act_name[i] for c in ("adhesion", "head", "mouth", "antennae", "wings", "abdomen", "legs")
+                         for i in (b.walker["ctrl_indices"][c] or [])],
+    }
+    with open(os.path.join(OUT, "fly_ball.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote ball model: nbody", b.nbody, "nq", b.nq, "nv", b.nv, "nu", b.nu, "ngeom", len(b.geom_bodyid))
 
 
 if __name__ == "__main__":
