@@ -63,7 +63,7 @@ def read_blob(path: str) -> dict:
     return out
 
 
-def model_tensors(m, L=None) -> dict:
+def model_tensors(m, L=None, with_collision=False) -> dict:
     """Flatten a `CompiledModel` + `LinkModel` (+ the walker's action/observation bookkeeping)."""
     w = m.walker
     nu = m.nu
@@ -115,7 +115,7 @@ def model_tensors(m, L=None) -> dict:
         "wing_jnt": np.array(wing, dtype=np.int32),
         "obs_jnt": np.array(obs_j, dtype=np.int32),
     }
-    if len(m.geom_bodyid):  # contact-capable models (walk_on_ball)
+    if with_collision:  # contact-capable models (walk_on_ball)
         sid = {n: k for k, n in enumerate(m.sites_name)}
         app = [sid[n] for n in ("claw_T1_left", "claw_T1_right", "claw_T2_left", "claw_T2_right", "claw_T3_left",
                                 "claw_T3_right", "head") if n in sid]  # `fruitfly.py:421-447`

@@ -16,6 +16,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_DIR, "_build", "libfly_oracle.so")
 
 FO_NO_FLUID, FO_NO_LIMIT, FO_NO_DAMPER, FO_NO_SPRING, FO_NO_GRAVITY, FO_NO_ACTUATION = 1, 2, 4, 8, 16, 32
+FO_NO_CONTACT, FO_NO_NOSLIP, FO_NO_ADHESION = 64, 128, 256
 
 
 def build(force: bool = False) -> str:
@@ -46,6 +47,17 @@ def lib():
                   "fo_cvel", "fo_sensors", "fo_time"):
             getattr(L, n).restype = dp
             getattr(L, n).argtypes = [vp]
+        for n in ("fo_na", "fo_ngeom", "fo_npair", "fo_npair_unsupported", "fo_nsite", "fo_ntouch", "fo_nforce",
+                  "fo_ncon", "fo_near_unsupported"):
+            getattr(L, n).restype = C.c_int
+            getattr(L, n).argtypes = [vp]
+        for n in ("fo_act", "fo_efc_force", "fo_efc_J", "fo_efc_aref", "fo_efc_D", "fo_sens_touch", "fo_sens_force",
+                  "fo_site_xpos", "fo_geom_xpos", "fo_qpos_spring"):
+            getattr(L, n).restype = dp
+            getattr(L, n).argtypes = [vp]
+        L.fo_efc_type.restype = ip
+        L.fo_efc_type.argtypes = [vp]
+        L.fo_contact_info.argtypes = [vp, C.c_int, dp]
         L.fo_nefc.restype = C.c_int
         L.fo_nefc.argtypes = [vp]
         L.fo_solver_iter.restype = C.c_int
@@ -80,6 +92,22 @@ def lib():
         L.fo_env_wbpg_reset.argtypes = [vp, C.c_double, dp, dp]
         L.fo_env_wbpg_step.argtypes = [vp, C.c_double, dp]
         L.fo_test_quat.argtypes = [C.c_int, dp, dp, dp]
+        L.fo_debug_constraint_eval.restype = C.c_double
+        L.fo_debug_constraint_eval.argtypes = [vp, vp, dp, dp, dp]
+        L.fo_debug_make_constraint.argtypes = [vp, vp]
+        L.fo_debug_qcqp2.restype = C.c_int
+        L.fo_debug_qcqp2.argtypes = [dp, dp, dp, dp, C.c_double]
+        L.fo_debug_ray_capsule.restype = C.c_double
+        L.fo_debug_ray_capsule.argtypes = [dp, dp, C.c_double, C.c_double]
+        L.fo_ball_env_new.restype = vp
+        L.fo_ball_env_new.argtypes = [vp, C.c_double, C.c_int]
+        L.fo_ball_env_data.restype = vp
+        L.fo_ball_env_data.argtypes = [vp]
+        L.fo_ball_env_set_pad_first_obs.argtypes = [vp, C.c_int]
+        L.fo_ball_env_request_reset.argtypes = [vp]
+        L.fo_ball_obs_dim.restype = C.c_int
+        L.fo_ball_obs_dim.argtypes = [vp]
+        L.fo_ball_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_env_counters.restype = C.c_int
         L.fo_env_counters.argtypes = [vp, ip, ip]
     return _lib
@@ -99,8 +127,10 @@ class OracleModel:
         self.ptr = self.L.fo_model_load(blob_path.encode())
         if not self.ptr:
             raise RuntimeError(f"cannot load {blob_path}")
-        for n in ("nq", "nv", "nu", "nbody", "njnt", "nM", "naction"):
+        for n in ("nq", "nv", "nu", "nbody", "njnt", "nM", "naction", "na", "ngeom", "npair", "npair_unsupported",
+                  "nsite", "ntouch", "nforce"):
             setattr(self, n, getattr(self.L, "fo_" + n)(self.ptr))
+        self.qpos_spring = np.ctypeslib.as_array(self.L.fo_qpos_spring(self.ptr), shape=(self.nq,))
 
     def set_flags(self, flags: int):
         self.L.fo_set_flags(self.ptr, flags)
@@ -136,6 +166,48 @@ class OracleData:
         self.cvel = view("fo_cvel", 6 * m.nbody).reshape(-1, 6)
         self.sensors = view("fo_sensors", 9)  # gyro, velocimeter, accelerometer
         self._time = view("fo_time", 1)
+        if m.na:
+            self.act = view("fo_act", m.na)
+        if m.ngeom:
+            self.sens_touch, self.sens_force = view("fo_sens_touch", m.ntouch), view("fo_sens_force", 3 * m.nforce).reshape(-1, 3)
+            self.site_xpos = view("fo_site_xpos", 3 * m.nsite).reshape(-1, 3)
+            self.geom_xpos = view("fo_geom_xpos", 3 * m.ngeom).reshape(-1, 3)
+            self.efc_force = view("fo_efc_force", 300)
+
+    @property
+    def ncon(self):
+        return self.L.fo_ncon(self.ptr)
+
+    @property
+    def near_unsupported(self):
+        return self.L.fo_near_unsupported(self.ptr)
+
+    @property
+    def nefc(self):
+        return self.L.fo_nefc(self.ptr)
+
+    def efc(self):
+        """(J [nefc, nv], aref, D, type) of the rows instantiated by the last forward pass."""
+        n, nv = self.nefc, self.m.nv
+        J = np.ctypeslib.as_array(self.L.fo_efc_J(self.ptr), shape=(n * nv,)).reshape(n, nv).copy()
+        aref = np.ctypeslib.as_array(self.L.fo_efc_aref(self.ptr), shape=(n,)).copy()
+        D = np.ctypeslib.as_array(self.L.fo_efc_D(self.ptr), shape=(n,)).copy()
+        ty = np.ctypeslib.as_array(self.L.fo_efc_type(self.ptr), shape=(n,)).copy()
+        return J, aref, D, ty
+
+    def constraint_eval(self, jar, hessian=False):
+        jar = np.ascontiguousarray(jar, dtype=np.float64)
+        force = np.zeros_like(jar)
+        H = np.zeros((self.m.nv, self.m.nv)) if hessian else None
+        cost = self.L.fo_debug_constraint_eval(self.m.ptr, self.ptr, _dp(jar), _dp(force), _dp(H) if hessian else None)
+        return cost, force, H
+
+    def contacts(self):
+        """Rows: geom1, geom2, dim, exclude, efc_adr, dist, pos[3], normal[3], mu, friction, includemargin, normal force."""
+        out = np.zeros((self.ncon, 16))
+        for i in range(self.ncon):
+            self.L.fo_contact_info(self.ptr, i, _dp(out[i]))
+        return out
 
     @property
     def time(self):
@@ -248,6 +320,42 @@ class OracleFlightEnv:
         t, s = C.c_int(), C.c_int()
         nr = self.L.fo_env_counters(self.ptr, C.byref(t), C.byref(s))
         return t.value, s.value, bool(nr)
+
+
+class OracleBallEnv:
+    """Single-instance float64 walk_on_ball env (`fly_envs.py:125-157`); one call = one control step."""
+
+    #: observation slices, in emission order
+    LAYOUT = (("accelerometer", 3), ("actuator_activation", 59), ("appendages_pos", 21), ("ball_qvel", 3), ("force", 18),
+              ("gyro", 3), ("joints_pos", 85), ("joints_vel", 85), ("touch", 6), ("velocimeter", 3), ("world_zaxis", 3))
+
+    def __init__(self, model: OracleModel, control_timestep=2e-3, time_limit_steps=1000):
+        self.model, self.L = model, model.L
+        self.ptr = self.L.fo_ball_env_new(model.ptr, float(control_timestep), int(time_limit_steps))
+        self.data = OracleData(model, self.L.fo_ball_env_data(self.ptr))
+        self.naction = model.naction
+        self.OBS = self.L.fo_ball_obs_dim(model.ptr)
+
+    def set_pad_first_obs(self, v: bool):
+        self.L.fo_ball_env_set_pad_first_obs(self.ptr, int(v))
+
+    def reset(self):
+        self.L.fo_ball_env_request_reset(self.ptr)
+        return self.step(np.zeros(self.naction))
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        obs = np.zeros(self.OBS)
+        r, dsc, st = C.c_double(), C.c_double(), C.c_int()
+        self.L.fo_ball_env_step(self.ptr, _dp(a), _dp(obs), C.byref(r), C.byref(dsc), C.byref(st))
+        return st.value, r.value, dsc.value, obs
+
+    def split(self, obs):
+        out, o = {}, 0
+        for name, n in self.LAYOUT:
+            out[name] = obs[o : o + n]
+            o += n
+        return out
 
 
 def rng_u64(seed, env, episode, stream):

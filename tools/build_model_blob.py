@@ -34,7 +34,7 @@ def main():
         json.dump(meta, f, indent=1)
     print("wrote", OUT, "nbody", m.nbody, "nv", m.nv, "nu", m.nu)
     b = build_ball_model()
-    write_blob(os.path.join(OUT, "fly_ball.ffmb"), model_tensors(b))
+    write_blob(os.path.join(OUT, "fly_ball.ffmb"), model_tensors(b, with_collision=True))
     meta = {
         "body_name": b.body_name, "jnt_name": b.jnt_name, "act_name": b.act_name, "ten_name": b.ten_name,
         "geom_name": b.geom_name, "site_name": b.sites_name,
