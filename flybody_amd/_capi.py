@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("FLYBODY_ENV_LIB") or os.path.join(_HERE, "csrc", "lib
 SYMBOLS = [
     "ffe_create_flight", "ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step",
     "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps",
-    "ffe_test_quat", "ffe_last_error", "ffe_version",
+    "ffe_test_quat", "ffe_last_error", "ffe_version", "ffe_create_walk_on_ball", "ffe_get_act", "ffe_set_act",
 ]
 
 
@@ -26,6 +26,11 @@ class FlightTask(C.Structure):
         ("ghost_accel_z", C.c_double), ("pad_first_obs", C.c_int32), ("physics_flags", C.c_int32),
         ("canonical_actions", C.c_int32), ("clip_actions", C.c_int32),
     ]
+
+
+class BallTask(C.Structure):
+    _fields_ = [("control_timestep", C.c_double), ("time_limit_steps", C.c_int32), ("pad_first_obs", C.c_int32),
+                ("physics_flags", C.c_int32), ("canonical_actions", C.c_int32), ("clip_actions", C.c_int32)]
 
 
 class Spec(C.Structure):
@@ -57,6 +62,11 @@ def lib():
     vp, fp, ip, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
     L.ffe_create_flight.restype = C.c_int
     L.ffe_create_flight.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FlightTask), C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.ffe_create_walk_on_ball.restype = C.c_int
+    L.ffe_create_walk_on_ball.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(BallTask), C.c_int, C.c_int, C.POINTER(vp)]
+    L.ffe_get_act.argtypes = [vp, dp, vp]
+    L.ffe_set_act.argtypes = [vp, dp, vp]
+    L.ffe_get_act.restype = L.ffe_set_act.restype = C.c_int
     L.ffe_destroy.argtypes = [vp]
     L.ffe_spec.argtypes = [vp, C.POINTER(Spec)]
     L.ffe_action_bounds.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]

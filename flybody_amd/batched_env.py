@@ -21,6 +21,7 @@ from .tasks.constants import _WING_PARAMS
 
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 FLIGHT_BLOB = os.path.join(_ASSETS, "fly_flight.ffmb")
+BALL_BLOB = os.path.join(_ASSETS, "fly_ball.ffmb")
 
 
 def _f64(a):
@@ -209,3 +210,73 @@ class BatchedFlyEnv:
         self._check(self._L.ffe_time_steps(self._h, action.data_ptr(), self._obs.data_ptr(), self._reward.data_ptr(),
                                            self._discount.data_ptr(), self._step_type.data_ptr(), int(iters), self._stream(), C.byref(ms)))
         return float(ms.value)
+
+
+class BatchedBallEnv(BatchedFlyEnv):
+    """B independent `walk_on_ball` environments (`fly_envs.py:125-157`) on one MI355X: a tethered fly on a floating
+    ball, 10 physics substeps (contacts, elliptic friction cones, noslip, adhesion, filtered actuators) per control step.
+    Same dm_env surface and hooks as `BatchedFlyEnv`; `get_state` returns qpos[B, 106] = ball quaternion + 102 hinges and
+    qvel[B, 105] = ball angular velocity + hinges."""
+
+    def __init__(self, *, batch_size: int, device: int = 0, time_limit: float = 2.0, control_timestep: float = 2e-3,
+                 pad_first_obs: bool = False, physics_flags: int = 0, canonical_actions: bool = False, clip_actions: bool = False,
+                 blob_path: str = BALL_BLOB):
+        import json
+
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedBallEnv needs a HIP device (MI355X); there is no CPU fallback")
+        self._torch = torch
+        self._L = _capi.lib()
+        self.batch_size = int(batch_size)
+        self.device = torch.device("cuda", device)
+        with open(blob_path, "rb") as f:
+            blob = f.read()
+        with open(os.path.splitext(blob_path)[0] + ".json") as f:
+            self._meta = json.load(f)
+        task = _capi.BallTask(control_timestep=float(control_timestep), time_limit_steps=int(round(time_limit / control_timestep)),
+                              pad_first_obs=int(pad_first_obs), physics_flags=int(physics_flags),
+                              canonical_actions=int(canonical_actions), clip_actions=int(clip_actions))
+        h = C.c_void_p()
+        rc = self._L.ffe_create_walk_on_ball(blob, len(blob), C.byref(task), self.batch_size, device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("ffe_create_walk_on_ball: " + self._L.ffe_last_error(None).decode())
+        self._h = h
+        self.canonical_actions = bool(canonical_actions)
+        self.spec = _capi.Spec()
+        self._check(self._L.ffe_spec(self._h, C.byref(self.spec)))
+        s = self.spec
+        amin, amax = (C.c_float * s.action_dim)(), (C.c_float * s.action_dim)()
+        self._check(self._L.ffe_action_bounds(self._h, amin, amax))
+        self._action_min, self._action_max = np.array(amin[:], dtype=np.float32), np.array(amax[:], dtype=np.float32)
+        B = self.batch_size
+        with torch.cuda.device(self.device):
+            self._obs = torch.zeros(B, s.obs_dim, dtype=torch.float32, device=self.device)
+            self._reward = torch.zeros(B, dtype=torch.float32, device=self.device)
+            self._discount = torch.zeros(B, dtype=torch.float32, device=self.device)
+            self._step_type = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._layout = collections.OrderedDict()
+        off = 0
+        for name, shape in (("accelerometer", (3,)), ("actuator_activation", (s.nu,)), ("appendages_pos", (21,)), ("ball_qvel", (3,)),
+                            ("force", (18,)), ("gyro", (3,)), ("joints_pos", (s.n_obs_joints,)), ("joints_vel", (s.n_obs_joints,)),
+                            ("touch", (6,)), ("velocimeter", (3,)), ("world_zaxis", (3,))):
+            self._layout["walker/" + name] = (off, shape)
+            off += int(np.prod(shape))
+        assert off == s.obs_dim
+
+    def set_next_trajectory_index(self, idx, phase):
+        raise NotImplementedError("walk_on_ball has no reference trajectories")
+
+    def get_act(self):
+        t = self._torch
+        act = t.empty(self.batch_size, self.spec.nu, dtype=t.float64, device=self.device)
+        self._check(self._L.ffe_get_act(self._h, act.data_ptr(), self._stream()))
+        return act
+
+    def set_act(self, act):
+        t = self._torch
+        act = act.to(device=self.device, dtype=t.float64).contiguous()
+        assert tuple(act.shape) == (self.batch_size, self.spec.nu)
+        self._check(self._L.ffe_set_act(self._h, act.data_ptr(), self._stream()))
+        t.cuda.current_stream(self.device).synchronize()

@@ -1,0 +1,1360 @@
+// ball_env.hip - MI355X (gfx950) batched walk_on_ball environment (ref: fly_envs.py:125-157, tasks/walk_on_ball.py).
+//
+// ONE 64-lane wavefront per environment, one launch = one control step (10 physics substeps of 2e-4 s, dm_control's
+// legacy mj_step2;mj_step1 order, buffered sensors, observation, reward, termination, auto-reset).  Lane mapping and
+// the model tables are described in ball_model.hpp.  Per substep (mj: mj_step restated):
+//   stage 1  kinematics (level sweep), spatial inertias about the fixed thorax origin, velocities / bias accelerations
+//            (level sweep), inertia-box drag, composite inertias and subtree forces (level sweep), joint-space inertia
+//            (582 entries across the lanes) and its block factorisation, ball-capsule collision;
+//   stage 2  filtered actuators (+ adhesion through the contact normals), smooth acceleration, joint-limit and
+//            elliptic-cone contact rows, Newton iterations on the convex constraint cost (exact Hessian; the ball's
+//            3 dofs are eliminated through a Schur complement so the fly part keeps M's block sparsity), noslip sweeps,
+//            touch / force sensors, implicit-in-damping Euler integration.
+// Parity tests: tests/test_gpu_ball.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "ball_env.hpp"
+#include "ball_model.hpp"
+#include "dev_math.hpp"
+
+namespace ffb {
+using namespace dm;
+
+enum { BF_NO_FLUID = 1, BF_NO_LIMIT = 2, BF_NO_DAMPER = 4, BF_NO_SPRING = 8, BF_NO_GRAVITY = 16, BF_NO_ACTUATION = 32,
+       BF_NO_CONTACT = 64, BF_NO_NOSLIP = 128, BF_NO_ADHESION = 256 };
+constexpr int kMaxNewton = 12;
+constexpr int kLsIter = 14;
+
+struct alignas(16) BState {
+  float q[NDP], v[NDP], act[64];
+  float ballq[4], ballw[4];
+  int step_counter, needs_reset, overflow, iters, ncon, pad[3];
+};
+
+struct BTaskDev {
+  int time_limit_steps, pad_first_obs, flags, canonical, clip;
+};
+
+struct alignas(16) BTile {
+  float Q[NDP], V[NDP];
+  float4 X4[NDP];
+  float Mq[NMMAX], Lm[NMMAX], Lh[NMMAX];
+  float dinv_m[NDP], dinv_h[NDP], dadd[NDP];
+  float C[NDP][6];
+  union {
+    float F[NDP][6];    // crb * cdof during the inertia assembly
+    float lk[NL][16];   // link exchange of the level sweeps: pose (7) | velocity + acceleration (12) | crb + force (16)
+    struct { float A[2 * NC][2 * NC + 1], b[2 * NC], f[2 * NC]; } ns;  // noslip: unregularised tangential block
+  };
+  float frc[64];
+  int c_link[NC], c_blk[NC], c_excl[NC];
+  unsigned c_amask[NC];
+  float c_pos[NC][3], c_frame[NC][9], c_dist[NC];
+  float c_J[NC][3][NCH + 2], c_JB[NC][3][NCH + 2], c_Jb[NC][3][3], c_JBb[NC][3][3];
+  float c_D[NC], c_mu[NC], c_aref[NC][3], c_f[NC][3], c_Hc[NC][9], c_jar[NC][3], c_jd[NC][3], c_w[NC][3];
+  float sens[32];  // running sums of the buffered sensors: force 18, touch 6
+};
+
+// ------------------------------------------------------------------------------------------------ per-lane context
+struct Ctx {
+  const BallModel *M;
+  BTile *T;
+  int lane, flags;
+  // link constants
+  int parent, depth, nchild, ch0, ch1, ch2, ndof;
+  V3 pos, ipos, inertia;
+  Q4 quat, iquat;
+  float mass, fl[8];
+  // dof slots (3 = haltere on lanes 0, 1)
+  int sdof[4], sblk[4], sli[4], slim[4];
+  V3 axis[3], jpos[3];
+  float stiff[4], sref[4], damp[4], lo[4], hi[4], invw[4], sK[4], sB[4];
+  float q[4], v[4];
+  // stage-1 results
+  V3 xp, xip;
+  M3 xmat, ximat;
+  Q4 xq;
+  S6 cdof[3], cdd[3], cvel, cfrc_ext_unused;
+  I10 cinert;
+  float fnb[4];
+  // ball (uniform across lanes)
+  Q4 bq;
+  V3 bw, btau;
+  int nc;
+  // entries of the joint-space inertia owned by this lane
+  unsigned emeta[ECAP];
+  unsigned eadr[ECAP];   // adr | fmask << 16
+  unsigned estep[ECAP];  // rowstep | colstep << 8 | diag adr << 16
+};
+
+__device__ __forceinline__ bool slot_on(const Ctx &c, int s) { return c.sdof[s] >= 0; }
+
+// ------------------------------------------------------------------------------------------------ block factorisation
+// mj: mj_factorI restricted to M's 12 independent blocks, all blocks in lock step: at step s every block eliminates its
+// s-th pivot from the leaf end; an entry (i, j) is touched when i is a proper ancestor of that pivot k:
+//   L[i][j] -= L[k][i] * L[k][j] / L[k][k]   (all values unscaled until the final pass, exactly as mj_factorI orders it)
+// `src` + diag(dadd) is factorised into `dst`; dinv receives 1 / D.
+__device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, float *dst, float *dinv) {
+  BTile &T = *c.T;
+  const BallModel &M = *c.M;
+#pragma unroll
+  for (int t = 0; t < ECAP; t++) {
+    if (c.emeta[t] >> 31) {
+      const unsigned adr = c.eadr[t] & 0xffffu, i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu;
+      float vv = src[adr];
+      if (use_add && i == j) vv += T.dadd[i];
+      dst[adr] = vv;
+    }
+  }
+  DM_SYNC();
+#pragma unroll 1
+  for (int s = 0; s < NSTEP - 1; s++) {
+#pragma unroll
+    for (int t = 0; t < ECAP; t++) {
+      if ((c.eadr[t] >> (16 + s)) & 1u) {
+        const unsigned meta = c.emeta[t], blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu, lij = (meta >> 20) & 0xfu;
+        const unsigned p = M.piv[s][blk], mk = p & 0xffffu, am = p >> 16;
+        const unsigned oi = __popc(am & ~((2u << lii) - 1u)), oj = __popc(am & ~((2u << lij) - 1u));
+        const float lkk = dst[mk], lki = dst[mk + oi], lkj = dst[mk + oj];
+        const unsigned adr = c.eadr[t] & 0xffffu;
+        dst[adr] -= lki * lkj / lkk;
+      }
+    }
+    DM_SYNC();
+  }
+#pragma unroll
+  for (int t = 0; t < ECAP; t++) {
+    if (c.emeta[t] >> 31) {
+      const unsigned adr = c.eadr[t] & 0xffffu, i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu, dadr = c.estep[t] >> 16;
+      const float dg = dst[dadr];
+      if (i == j) dinv[i] = 1.f / dg;
+    }
+  }
+  DM_SYNC();
+#pragma unroll
+  for (int t = 0; t < ECAP; t++) {
+    if (c.emeta[t] >> 31) {
+      const unsigned adr = c.eadr[t] & 0xffffu, i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu;
+      if (i != j) dst[adr] *= dinv[i];
+    }
+  }
+  DM_SYNC();
+}
+
+// mj: mj_solveLD on T.X4 (four right-hand sides at once), blocks in lock step: rows leaf -> root, D^-1, columns root -> leaf
+__device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv) {
+  BTile &T = *c.T;
+#pragma unroll 1
+  for (int s = 0; s < NSTEP - 1; s++) {
+#pragma unroll
+    for (int t = 0; t < ECAP; t++) {
+      const unsigned meta = c.emeta[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
+      if ((meta >> 31) && i != j && (c.estep[t] & 0xffu) == (unsigned)s) {
+        const float l = L[c.eadr[t] & 0xffffu];
+        const float4 xi = T.X4[i];
+        float4 xj = T.X4[j];
+        xj.x -= l * xi.x; xj.y -= l * xi.y; xj.z -= l * xi.z; xj.w -= l * xi.w;
+        T.X4[j] = xj;
+      }
+    }
+    DM_SYNC();
+  }
+  for (int f = c.lane; f < ND; f += 64) {
+    const float dv = dinv[f];
+    float4 x = T.X4[f];
+    x.x *= dv; x.y *= dv; x.z *= dv; x.w *= dv;
+    T.X4[f] = x;
+  }
+  DM_SYNC();
+#pragma unroll 1
+  for (int r = 0; r < NSTEP - 1; r++) {
+#pragma unroll
+    for (int t = 0; t < ECAP; t++) {
+      const unsigned meta = c.emeta[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
+      if ((meta >> 31) && i != j && ((c.estep[t] >> 8) & 0xffu) == (unsigned)r) {
+        const float l = L[c.eadr[t] & 0xffffu];
+        const float4 xj = T.X4[j];
+        float4 xi = T.X4[i];
+        xi.x -= l * xj.x; xi.y -= l * xj.y; xi.z -= l * xj.z; xi.w -= l * xj.w;
+        T.X4[i] = xi;
+      }
+    }
+    DM_SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ impedance
+// mj: getimpedance (margin folded into `x` by the caller: x = |pos - margin|)
+__device__ __forceinline__ float impedance(float d0, float d1, float width, float mid, float power, float x) {
+  d0 = fminf(fmaxf(d0, 1e-4f), 0.9999f); d1 = fminf(fmaxf(d1, 1e-4f), 0.9999f);
+  width = fmaxf(0.f, width); mid = fminf(fmaxf(mid, 1e-4f), 0.9999f); power = fmaxf(1.f, power);
+  if (d0 == d1 || width <= 1e-15f) return 0.5f * (d0 + d1);
+  x = x / width;
+  if (x >= 1.f) return d1;
+  if (x <= 0.f) return d0;
+  float y;
+  if (power == 1.f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
+  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  return d0 + y * (d1 - d0);
+}
+
+// ------------------------------------------------------------------------------------------------ stage 1
+__device__ __forceinline__ void stage1(Ctx &c) {
+  BTile &T = *c.T;
+  const BallModel &M = *c.M;
+  const int lane = c.lane;
+  const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
+  // ---- mj: mj_kinematics, one tree level per sweep
+  V3 axw[3], anc[3];
+#pragma unroll 1
+  for (int d = 1; d <= M.maxdepth; d++) {
+    if (c.depth == d) {
+      Q4 pq = {1.f, 0.f, 0.f, 0.f};
+      V3 pp = {0.f, 0.f, 0.f};
+      if (c.parent >= 0) { const float *p = T.lk[c.parent]; pp = {p[0], p[1], p[2]}; pq = {p[3], p[4], p[5], p[6]}; }
+      V3 xp = pp + qrot(pq, c.pos);
+      Q4 xq = qmul(pq, c.quat);
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        if (s < c.ndof) {
+          anc[s] = xp + qrot(xq, c.jpos[s]);
+          axw[s] = qrot(xq, c.axis[s]);
+          xq = qmul(xq, axis_angle(c.axis[s], c.q[s]));
+          xp = anc[s] - qrot(xq, c.jpos[s]);
+        }
+      }
+      xq = qnormalize(xq);
+      c.xp = xp; c.xq = xq;
+      float *o = T.lk[lane];
+      o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
+    }
+    DM_SYNC();
+  }
+  c.xmat = q2m(c.xq);
+  c.xip = c.xp + mv(c.xmat, c.ipos);
+  c.ximat = q2m(qmul(c.xq, c.iquat));
+  // ---- mj: mj_comPos with the fixed thorax origin as the reference point
+  c.cinert = inert_com(c.inertia, c.ximat, c.xip - c0, c.mass);
+#pragma unroll
+  for (int s = 0; s < 3; s++) c.cdof[s] = s < c.ndof ? mk6(axw[s], cross(axw[s], c0 - anc[s])) : zero6();
+  // ---- mj: mj_comVel + the acceleration half of mj_rne, one level per sweep
+  S6 cacc = zero6();
+#pragma unroll 1
+  for (int d = 1; d <= M.maxdepth; d++) {
+    if (c.depth == d) {
+      S6 pv = zero6(), pa = {0.f, 0.f, 0.f, 0.f, 0.f, (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz};
+      if (c.parent >= 0) { const float *p = T.lk[c.parent]; pv = ld6(p); pa = ld6(p + 6); }
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        if (s < c.ndof) {
+          c.cdd[s] = cross_motion(pv, c.cdof[s]);
+          pv = pv + c.v[s] * c.cdof[s];
+          pa = pa + c.v[s] * c.cdd[s];
+        }
+      }
+      c.cvel = pv; cacc = pa;
+      st6(T.lk[lane], pv); st6(T.lk[lane] + 6, pa);
+    }
+    DM_SYNC();
+  }
+  // ---- body forces: rigid-body bias (mj_rne) minus inertia-box drag (mj_inertiaBoxFluidModel), about c0
+  S6 ftot;
+  {
+    const S6 t1 = mul_inert(c.cinert, cacc), t2 = mul_inert(c.cinert, c.cvel);
+    ftot = t1 + cross_force(c.cvel, t2);
+    if (!(c.flags & BF_NO_FLUID)) {
+      const V3 r = c.xip - c0;
+      const V3 wl = mtv(c.ximat, ang(c.cvel)), vl = mtv(c.ximat, lin(c.cvel) + cross(ang(c.cvel), r));
+      const V3 Tl = {-c.fl[0] * wl.x - c.fl[5] * fabsf(wl.x) * wl.x, -c.fl[0] * wl.y - c.fl[6] * fabsf(wl.y) * wl.y, -c.fl[0] * wl.z - c.fl[7] * fabsf(wl.z) * wl.z};
+      const V3 Fl = {-c.fl[1] * vl.x - c.fl[2] * fabsf(vl.x) * vl.x, -c.fl[1] * vl.y - c.fl[3] * fabsf(vl.y) * vl.y, -c.fl[1] * vl.z - c.fl[4] * fabsf(vl.z) * vl.z};
+      const V3 Tw = mv(c.ximat, Tl), Fw = mv(c.ximat, Fl);
+      ftot = ftot - mk6(Tw + cross(r, Fw), Fw);
+    }
+  }
+  // ---- subtree sums (mj_crb's composite inertia and mj_rne's backward pass), leaves first
+  I10 crb = c.cinert;
+#pragma unroll 1
+  for (int d = M.maxdepth; d >= 1; d--) {
+    if (c.depth == d) {
+      if (c.nchild > 0) { const float *p = T.lk[c.ch0]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
+      if (c.nchild > 1) { const float *p = T.lk[c.ch1]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
+      if (c.nchild > 2) { const float *p = T.lk[c.ch2]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
+      st10(T.lk[lane], crb); st6(T.lk[lane] + 10, ftot);
+    }
+    DM_SYNC();
+  }
+  // ---- smooth joint forces without actuation: springs, dampers, -(bias - drag)
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    float f = 0.f;
+    if (s < c.ndof) {
+      if (!(c.flags & BF_NO_SPRING)) f -= c.stiff[s] * (c.q[s] - c.sref[s]);
+      if (!(c.flags & BF_NO_DAMPER)) f -= c.damp[s] * c.v[s];
+      f -= dot6(c.cdof[s], ftot);
+    }
+    c.fnb[s] = f;
+  }
+  c.fnb[3] = 0.f;
+  if (slot_on(c, 3)) {  // halteres: closed form (see ball_model.hpp)
+    float sn, cs;
+    sincosf(c.q[3], &sn, &cs);
+    float f = 0.f;
+    if (!(c.flags & BF_NO_SPRING)) f -= c.stiff[3] * (c.q[3] - c.sref[3]);
+    if (!(c.flags & BF_NO_DAMPER)) f -= c.damp[3] * c.v[3];
+    if (!(c.flags & BF_NO_GRAVITY)) f += M.x_Gc[lane] * cs + M.x_Gs[lane] * sn;
+    if (!(c.flags & BF_NO_FLUID)) f -= M.x_cv[lane] * c.v[3] + M.x_cq[lane] * fabsf(c.v[3]) * c.v[3];
+    c.fnb[3] = f;
+  }
+  // ball: isotropic sphere about its centre, only the box drag acts (mj_inertiaBoxFluidModel in the inertial frame)
+  {
+    V3 tau = {0.f, 0.f, 0.f};
+    if (!(c.flags & BF_NO_FLUID)) {
+      const M3 Ri = q2m(Q4{M.b_iquat[0], M.b_iquat[1], M.b_iquat[2], M.b_iquat[3]});
+      const V3 wl = mtv(Ri, c.bw);
+      const V3 Tl = {-M.b_fl[0] * wl.x - M.b_fl[5] * fabsf(wl.x) * wl.x, -M.b_fl[0] * wl.y - M.b_fl[6] * fabsf(wl.y) * wl.y, -M.b_fl[0] * wl.z - M.b_fl[7] * fabsf(wl.z) * wl.z};
+      tau = mv(Ri, Tl);
+    }
+    c.btau = tau;
+  }
+  // ---- mj: mj_crb joint-space inertia, one entry per (lane, slot t)
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    if (s < c.ndof) { st6(T.F[c.sdof[s]], mul_inert(crb, c.cdof[s])); st6(T.C[c.sdof[s]], c.cdof[s]); }
+  }
+  if (slot_on(c, 3)) { st6(T.F[c.sdof[3]], S6{M.x_M[lane], 0.f, 0.f, 0.f, 0.f, 0.f}); st6(T.C[c.sdof[3]], S6{1.f, 0.f, 0.f, 0.f, 0.f, 0.f}); }
+  DM_SYNC();
+#pragma unroll
+  for (int t = 0; t < ECAP; t++) {
+    if (c.emeta[t] >> 31) {
+      const unsigned i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu;
+      float mij = dot6(ld6(T.C[j]), ld6(T.F[i]));
+      if (i == j) mij += M.d_arm[i];
+      T.Mq[c.eadr[t] & 0xffffu] = mij;
+    }
+  }
+  DM_SYNC();
+  factor(c, T.Mq, false, T.Lm, T.dinv_m);
+  // ---- mj: mj_collision, ball (geom1, sphere) against this link's capsule: mjc_SphereCapsule
+  bool hit = false;
+  float dist = 0.f;
+  V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
+  if (M.g_has[lane] && !(c.flags & BF_NO_CONTACT)) {
+    const V3 bc = {M.b_center[0], M.b_center[1], M.b_center[2]};
+    const V3 gp = c.xp + mv(c.xmat, V3{M.g_pos[0][lane], M.g_pos[1][lane], M.g_pos[2][lane]});
+    const V3 ax = mv(c.xmat, V3{M.g_axis[0][lane], M.g_axis[1][lane], M.g_axis[2][lane]});
+    const float half = M.g_half[lane], x = fminf(fmaxf(dot(ax, bc - gp), -half), half);
+    const V3 dif = gp + x * ax - bc;
+    const float cd = sqrtf(dot(dif, dif));
+    dist = cd - M.b_radius - M.g_rad[lane];
+    hit = cd <= M.g_margin[lane] + M.b_radius + M.g_rad[lane];
+    if (cd >= 1e-15f) nrm = (1.f / cd) * dif;
+    cpos = bc + (M.b_radius + 0.5f * dist) * nrm;
+  }
+  const unsigned long long bal = __ballot(hit);
+  const int idx = __popcll(bal & ((1ull << lane) - 1ull));
+  c.nc = min(__popcll(bal), NC);
+  if (hit && idx < NC) {
+    T.c_link[idx] = lane;
+    const int last = c.ndof == 1 ? c.sdof[0] : (c.ndof == 2 ? c.sdof[1] : c.sdof[2]);
+    T.c_blk[idx] = M.d_blk[last]; T.c_amask[idx] = M.d_amask[last];
+    T.c_excl[idx] = dist >= M.g_margin[lane] - M.g_gap[lane] ? 1 : 0;
+    T.c_dist[idx] = dist;
+    T.c_pos[idx][0] = cpos.x; T.c_pos[idx][1] = cpos.y; T.c_pos[idx][2] = cpos.z;
+    // mj: mju_makeFrame
+    V3 t1 = (nrm.y < 0.5f && nrm.y > -0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
+    t1 = t1 - dot(nrm, t1) * nrm;
+    t1 = (1.f / sqrtf(dot(t1, t1))) * t1;
+    const V3 t2 = cross(nrm, t1);
+    float *fr = T.c_frame[idx];
+    fr[0] = nrm.x; fr[1] = nrm.y; fr[2] = nrm.z; fr[3] = t1.x; fr[4] = t1.y; fr[5] = t1.z; fr[6] = t2.x; fr[7] = t2.y; fr[8] = t2.z;
+  }
+  DM_SYNC();
+}
+
+// sum over the contacts whose chain contains fly dof (blk, li) of  sum_r J[c][r][p] * w[c][r]
+__device__ __forceinline__ float contact_gather(const Ctx &c, int blk, int li, const float (*w)[3]) {
+  const BTile &T = *c.T;
+  float acc = 0.f;
+  for (int k = 0; k < c.nc; k++) {
+    if (T.c_blk[k] == blk && ((T.c_amask[k] >> li) & 1u)) {
+      const int p = __popc(T.c_amask[k] & ((1u << li) - 1u));
+      acc += T.c_J[k][0][p] * w[k][0] + T.c_J[k][1][p] * w[k][1] + T.c_J[k][2][p] * w[k][2];
+    }
+  }
+  return acc;
+}
+
+// mj: PrimalUpdateConstraint for one elliptic condim-3 contact (cost zones: DESIGN.md)
+__device__ __forceinline__ void cone_force(float D, float mu, float j0, float j1, float j2, float &f0, float &f1, float &f2, float *Hc) {
+  const float N = j0 * mu, U1 = j1 * mu, U2 = j2 * mu, Tn = sqrtf(U1 * U1 + U2 * U2);
+  if (Hc) for (int k = 0; k < 9; k++) Hc[k] = 0.f;
+  if (N >= mu * Tn || (Tn <= 0.f && N >= 0.f)) { f0 = f1 = f2 = 0.f; return; }
+  if (mu * N + Tn <= 0.f || (Tn <= 0.f && N < 0.f)) {
+    f0 = -D * j0; f1 = -D * j1; f2 = -D * j2;
+    if (Hc) { Hc[0] = D; Hc[4] = D; Hc[8] = D; }
+    return;
+  }
+  const float Dm = D / fmaxf(1e-15f, mu * mu * (1.f + mu * mu)), NT = N - mu * Tn;
+  f0 = -Dm * NT * mu;
+  f1 = -f0 / Tn * U1 * mu;
+  f2 = -f0 / Tn * U2 * mu;
+  if (Hc) {
+    const float a = mu * N / (Tn * Tn * Tn), bd = mu * mu - mu * N / Tn, s2 = Dm * mu * mu;
+    Hc[0] = s2;
+    Hc[1] = Hc[3] = s2 * (-mu * U1 / Tn);
+    Hc[2] = Hc[6] = s2 * (-mu * U2 / Tn);
+    Hc[4] = s2 * (a * U1 * U1 + bd);
+    Hc[8] = s2 * (a * U2 * U2 + bd);
+    Hc[5] = Hc[7] = s2 * (a * U1 * U2);
+  }
+}
+
+// mj: mju_QCQP2 with equal friction coefficients d: min 1/2 x'Ax + x'b, |x| <= d r
+__device__ __forceinline__ bool qcqp2(float &x0, float &x1, float A00, float A01, float A11, float b0, float b1, float d, float r) {
+  const float B0 = b0 * d, B1 = b1 * d, P00 = A00 * d * d, P01 = A01 * d * d, P11 = A11 * d * d, r2 = r * r;
+  float la = 0.f, v0 = 0.f, v1 = 0.f;
+  bool active = false;
+  for (int it = 0; it < 20; it++) {
+    const float det = (P00 + la) * (P11 + la) - P01 * P01;
+    if (det < 1e-10f) { x0 = x1 = 0.f; return false; }
+    const float i00 = (P11 + la) / det, i11 = (P00 + la) / det, i01 = -P01 / det;
+    v0 = -i00 * B0 - i01 * B1; v1 = -i01 * B0 - i11 * B1;
+    const float val = v0 * v0 + v1 * v1 - r2;
+    if (val < 1e-10f) break;
+    const float deriv = -2.f * (i00 * v0 * v0 + i11 * v1 * v1 + 2.f * i01 * v0 * v1);
+    const float delta = -val / deriv;
+    if (delta < 1e-10f) break;
+    la += delta;
+    active = true;
+  }
+  x0 = v0 * d; x1 = v1 * d;
+  return active;
+}
+
+// ------------------------------------------------------------------------------------------------ stage 2
+// Returns the per-slot accelerations used for the termination guard through c (qacc in fa[]), integrates the state.
+__device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, float &act_out, bool integrate, int &iters_out, float *qacc_norm2) {
+  BTile &T = *c.T;
+  const BallModel &M = *c.M;
+  const int lane = c.lane;
+  const int nc = c.nc;
+  const float h = M.h;
+  const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
+  const V3 bc = {M.b_center[0], M.b_center[1], M.b_center[2]};
+#pragma unroll
+  for (int s = 0; s < 4; s++) if (slot_on(c, s)) { T.Q[c.sdof[s]] = c.q[s]; T.V[c.sdof[s]] = c.v[s]; }
+  DM_SYNC();
+  // ---- mj: mj_fwdActuation: first-order activation filter, affine position servo on the activation
+  float act_dot = 0.f;
+  if (lane < NU) {
+    float force = 0.f;
+    if (!(c.flags & BF_NO_ACTUATION)) {
+      float ctrl = ctrl_reg;
+      if (M.a_climited[lane]) ctrl = fminf(fmaxf(ctrl, M.a_clo[lane]), M.a_chi[lane]);
+      act_dot = (ctrl - act_reg) / M.a_tau[lane];
+      float length = 0.f, vel = 0.f;
+      for (int w = 0; w < M.a_nwrap[lane]; w++) { const int f = M.a_wdof[w][lane]; length += M.a_wcoef[w][lane] * T.Q[f]; vel += M.a_wcoef[w][lane] * T.V[f]; }
+      force = M.a_gain[lane] * act_reg + M.a_b0[lane] + M.a_b1[lane] * length + M.a_b2[lane] * vel;
+      if (M.a_flimited[lane]) force = fminf(fmaxf(force, M.a_flo[lane]), M.a_fhi[lane]);
+      if (M.a_trn[lane] == 2 && (c.flags & BF_NO_ADHESION)) force = 0.f;
+    }
+    T.frc[lane] = force;
+  }
+  act_out = act_reg + h * act_dot;
+  // ---- contact rows: Jacobians over the chain dofs (jac2 - jac1, geom1 = ball), impedance, reference acceleration
+  Q4 bq = c.bq;
+  const M3 Rb = q2m(bq);
+  DM_SYNC();
+  for (int item = lane; item < nc * NCH; item += 64) {
+    const int k = item / NCH, p = item - k * NCH, l = T.c_link[k], f = M.l_chain[p][l];
+    float j0 = 0.f, j1 = 0.f, j2 = 0.f;
+    if (f >= 0) {
+      const S6 cd = ld6(T.C[f]);
+      const V3 r = V3{T.c_pos[k][0], T.c_pos[k][1], T.c_pos[k][2]} - c0;
+      const V3 u = lin(cd) + cross(ang(cd), r);
+      const float *fr = T.c_frame[k];
+      j0 = fr[0] * u.x + fr[1] * u.y + fr[2] * u.z; j1 = fr[3] * u.x + fr[4] * u.y + fr[5] * u.z; j2 = fr[6] * u.x + fr[7] * u.y + fr[8] * u.z;
+    }
+    T.c_J[k][0][p] = j0; T.c_J[k][1][p] = j1; T.c_J[k][2][p] = j2;
+  }
+  if (lane < nc) {
+    const V3 r = V3{T.c_pos[lane][0], T.c_pos[lane][1], T.c_pos[lane][2]} - bc;
+    const float *fr = T.c_frame[lane];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const V3 ek = {k == 0 ? Rb.m0 : (k == 1 ? Rb.m1 : Rb.m2), k == 0 ? Rb.m3 : (k == 1 ? Rb.m4 : Rb.m5), k == 0 ? Rb.m6 : (k == 1 ? Rb.m7 : Rb.m8)};
+      const V3 u = cross(ek, r);
+      T.c_Jb[lane][0][k] = -(fr[0] * u.x + fr[1] * u.y + fr[2] * u.z);
+      T.c_Jb[lane][1][k] = -(fr[3] * u.x + fr[4] * u.y + fr[5] * u.z);
+      T.c_Jb[lane][2][k] = -(fr[6] * u.x + fr[7] * u.y + fr[8] * u.z);
+    }
+  }
+  DM_SYNC();
+  // per-contact parameters (lane = contact) and the adhesion pull (mj: mj_transmission mjTRN_BODY: -force along the normal row)
+  if (lane < nc) {
+    const int l = T.c_link[lane], nch = M.l_nchain[l];
+    float vel[3] = {0.f, 0.f, 0.f};
+    for (int p = 0; p < nch; p++) {
+      const float vv = T.V[M.l_chain[p][l]];
+      vel[0] += T.c_J[lane][0][p] * vv; vel[1] += T.c_J[lane][1][p] * vv; vel[2] += T.c_J[lane][2][p] * vv;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) vel[r] += T.c_Jb[lane][r][0] * c.bw.x + T.c_Jb[lane][r][1] * c.bw.y + T.c_Jb[lane][r][2] * c.bw.z;
+    const float incl = M.g_margin[l] - M.g_gap[l], dist = T.c_dist[lane];
+    const float imp = impedance(M.g_solimp[0][l], M.g_solimp[1][l], M.g_solimp[2][l], M.g_solimp[3][l], M.g_solimp[4][l], fabsf(dist - incl));
+    const float R0 = fmaxf(1e-15f, (1.f - imp) * M.g_invw[l] / imp);
+    T.c_D[lane] = T.c_excl[lane] ? 0.f : 1.f / R0;
+    T.c_mu[lane] = M.g_fric[l];
+    T.c_aref[lane][0] = -M.g_B[l] * vel[0] - M.g_K[l] * imp * (dist - incl);
+    T.c_aref[lane][1] = -M.g_B[l] * vel[1];
+    T.c_aref[lane][2] = -M.g_B[l] * vel[2];
+    const int adh = M.l_adh[l];
+    T.c_w[lane][0] = adh >= 0 ? -T.frc[adh] : 0.f; T.c_w[lane][1] = 0.f; T.c_w[lane][2] = 0.f;
+  }
+  DM_SYNC();
+  // ---- smooth forces and accelerations (mj: mj_fwdAcceleration)
+  float qs[4], am[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    qs[s] = 0.f;
+    if (slot_on(c, s)) {
+      float f = c.fnb[s];
+      const int a0 = M.s_act[0][s][lane], a1 = M.s_act[1][s][lane];
+      if (a0 >= 0) f += M.s_actcoef[0][s][lane] * T.frc[a0];
+      if (a1 >= 0) f += M.s_actcoef[1][s][lane] * T.frc[a1];
+      if (nc) f += contact_gather(c, c.sblk[s], c.sli[s], T.c_w);
+      qs[s] = f;
+      T.X4[c.sdof[s]] = make_float4(f, 0.f, 0.f, 0.f);
+    }
+  }
+  V3 qsb = c.btau;
+  for (int k = 0; k < nc; k++) {
+    qsb.x += T.c_Jb[k][0][0] * T.c_w[k][0]; qsb.y += T.c_Jb[k][0][1] * T.c_w[k][0]; qsb.z += T.c_Jb[k][0][2] * T.c_w[k][0];
+  }
+  DM_SYNC();
+  solve4(c, T.Lm, T.dinv_m);
+#pragma unroll
+  for (int s = 0; s < 4; s++) am[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
+  const float Ib = M.b_I;
+  const V3 amb = (1.f / Ib) * qsb;
+  // ---- joint-limit rows (mj: mj_instantiateLimit, margin 0): sign, D, aref per slot
+  float lsgn[4], lD[4], laref[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    lsgn[s] = 0.f; lD[s] = 0.f; laref[s] = 0.f;
+    if (slot_on(c, s) && c.slim[s] && !(c.flags & BF_NO_LIMIT)) {
+      const float dlo = c.q[s] - c.lo[s], dhi = c.hi[s] - c.q[s];
+      float dist = 0.f;
+      if (dlo < 0.f) { lsgn[s] = 1.f; dist = dlo; }
+      else if (dhi < 0.f) { lsgn[s] = -1.f; dist = dhi; }
+      if (lsgn[s] != 0.f) {
+        const float imp = impedance(M.s_solimp[0][s][lane], M.s_solimp[1][s][lane], M.s_solimp[2][s][lane], M.s_solimp[3][s][lane], M.s_solimp[4][s][lane], fabsf(dist));
+        lD[s] = 1.f / fmaxf(1e-15f, (1.f - imp) * c.invw[s] / imp);
+        laref[s] = -c.sB[s] * (lsgn[s] * c.v[s]) - c.sK[s] * imp * dist;
+      }
+    }
+  }
+  // ---- mj: mj_fwdConstraint - Newton on 1/2 (a - a_s)' M (a - a_s) + s(J a - aref), started at a_s
+  float a[4], Ma[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) { a[s] = am[s]; Ma[s] = qs[s]; }
+  V3 ab = amb;
+  int any_lim = 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) any_lim |= (lsgn[s] != 0.f);
+  int nact = 0;
+  for (int k = 0; k < nc; k++) nact += T.c_excl[k] ? 0 : 1;
+  const bool constrained = __any(any_lim) || nact > 0;
+  int iters = 0;
+  float lf[4] = {0.f, 0.f, 0.f, 0.f};
+  if (constrained) {
+#pragma unroll 1
+    for (int it = 0; it < kMaxNewton; it++) {
+      // contact residuals, forces, local Hessians (lane = contact)
+#pragma unroll
+      for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
+      DM_SYNC();
+      if (lane < nc) {
+        const int l = T.c_link[lane], nch = M.l_nchain[l];
+        float jar[3] = {-T.c_aref[lane][0], -T.c_aref[lane][1], -T.c_aref[lane][2]};
+        for (int p = 0; p < nch; p++) {
+          const float av = T.X4[M.l_chain[p][l]].x;
+          jar[0] += T.c_J[lane][0][p] * av; jar[1] += T.c_J[lane][1][p] * av; jar[2] += T.c_J[lane][2][p] * av;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[lane][r][0] * ab.x + T.c_Jb[lane][r][1] * ab.y + T.c_Jb[lane][r][2] * ab.z;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, Hc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!T.c_excl[lane]) cone_force(T.c_D[lane], T.c_mu[lane], jar[0], jar[1], jar[2], f0, f1, f2, Hc);
+        T.c_jar[lane][0] = jar[0]; T.c_jar[lane][1] = jar[1]; T.c_jar[lane][2] = jar[2];
+        T.c_f[lane][0] = f0; T.c_f[lane][1] = f1; T.c_f[lane][2] = f2;
+        for (int k = 0; k < 9; k++) T.c_Hc[lane][k] = Hc[k];
+        // JB = Hc J over the chain and the ball columns
+        for (int p = 0; p < nch; p++) {
+          const float x0 = T.c_J[lane][0][p], x1 = T.c_J[lane][1][p], x2 = T.c_J[lane][2][p];
+          T.c_JB[lane][0][p] = Hc[0] * x0 + Hc[1] * x1 + Hc[2] * x2;
+          T.c_JB[lane][1][p] = Hc[3] * x0 + Hc[4] * x1 + Hc[5] * x2;
+          T.c_JB[lane][2][p] = Hc[6] * x0 + Hc[7] * x1 + Hc[8] * x2;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float x0 = T.c_Jb[lane][0][k], x1 = T.c_Jb[lane][1][k], x2 = T.c_Jb[lane][2][k];
+          T.c_JBb[lane][0][k] = Hc[0] * x0 + Hc[1] * x1 + Hc[2] * x2;
+          T.c_JBb[lane][1][k] = Hc[3] * x0 + Hc[4] * x1 + Hc[5] * x2;
+          T.c_JBb[lane][2][k] = Hc[6] * x0 + Hc[7] * x1 + Hc[8] * x2;
+        }
+      }
+      DM_SYNC();
+      // gradient (fly slots + ball), Hessian diagonal additions, coupling columns
+      float g[4], hadd[4], hfb[4][3];
+      float gn2 = 0.f, fn2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        g[s] = 0.f; hadd[s] = 0.f; lf[s] = 0.f; hfb[s][0] = hfb[s][1] = hfb[s][2] = 0.f;
+        if (slot_on(c, s)) {
+          float gg = Ma[s] - qs[s];
+          if (lsgn[s] != 0.f) {
+            const float r = lsgn[s] * a[s] - laref[s];
+            if (r < 0.f) { lf[s] = -lD[s] * r; gg -= lsgn[s] * lf[s]; hadd[s] = lD[s]; }
+          }
+          if (nc) {
+            gg -= contact_gather(c, c.sblk[s], c.sli[s], T.c_f);
+            for (int k = 0; k < nc; k++) {
+              if (T.c_blk[k] == c.sblk[s] && ((T.c_amask[k] >> c.sli[s]) & 1u)) {
+                const int p = __popc(T.c_amask[k] & ((1u << c.sli[s]) - 1u));
+                const float x0 = T.c_J[k][0][p], x1 = T.c_J[k][1][p], x2 = T.c_J[k][2][p];
+#pragma unroll
+                for (int m = 0; m < 3; m++) hfb[s][m] += x0 * T.c_JBb[k][0][m] + x1 * T.c_JBb[k][1][m] + x2 * T.c_JBb[k][2][m];
+              }
+            }
+          }
+          g[s] = gg;
+          gn2 += gg * gg; fn2 += Ma[s] * Ma[s] + qs[s] * qs[s];
+          T.dadd[c.sdof[s]] = hadd[s];
+        }
+      }
+      V3 gb = Ib * ab - qsb;
+      float Hbb[6] = {Ib, 0.f, 0.f, Ib, 0.f, Ib};  // xx xy xz yy yz zz
+      for (int k = 0; k < nc; k++) {
+        const float f0 = T.c_f[k][0], f1 = T.c_f[k][1], f2 = T.c_f[k][2];
+        gb.x -= T.c_Jb[k][0][0] * f0 + T.c_Jb[k][1][0] * f1 + T.c_Jb[k][2][0] * f2;
+        gb.y -= T.c_Jb[k][0][1] * f0 + T.c_Jb[k][1][1] * f1 + T.c_Jb[k][2][1] * f2;
+        gb.z -= T.c_Jb[k][0][2] * f0 + T.c_Jb[k][1][2] * f1 + T.c_Jb[k][2][2] * f2;
+        const float (*J)[3] = T.c_Jb[k];
+        const float (*B)[3] = T.c_JBb[k];
+        Hbb[0] += J[0][0] * B[0][0] + J[1][0] * B[1][0] + J[2][0] * B[2][0];
+        Hbb[1] += J[0][0] * B[0][1] + J[1][0] * B[1][1] + J[2][0] * B[2][1];
+        Hbb[2] += J[0][0] * B[0][2] + J[1][0] * B[1][2] + J[2][0] * B[2][2];
+        Hbb[3] += J[0][1] * B[0][1] + J[1][1] * B[1][1] + J[2][1] * B[2][1];
+        Hbb[4] += J[0][1] * B[0][2] + J[1][1] * B[1][2] + J[2][1] * B[2][2];
+        Hbb[5] += J[0][2] * B[0][2] + J[1][2] * B[1][2] + J[2][2] * B[2][2];
+      }
+      gn2 = wave_sum(gn2) + dot(gb, gb);
+      fn2 = wave_sum(fn2) + dot(qsb, qsb);
+      if (it > 0 && gn2 <= 1e-11f * fn2 + 1e-30f) break;
+      iters++;
+      // H_ff = M + diag(limit D) + sum_c J_f' Hc J_f  (same sparsity as M: a contact row only spans one chain)
+      DM_SYNC();
+#pragma unroll
+      for (int t = 0; t < ECAP; t++) {
+        if (c.emeta[t] >> 31) {
+          const unsigned meta = c.emeta[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu, blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu,
+                         lij = (meta >> 20) & 0xfu, adr = c.eadr[t] & 0xffffu;
+          float hv = T.Mq[adr];
+          if (i == j) hv += T.dadd[i];
+          for (int k = 0; k < nc; k++) {
+            if (T.c_blk[k] == (int)blk && ((T.c_amask[k] >> lii) & 1u)) {
+              const unsigned am_ = T.c_amask[k];
+              const int pi = __popc(am_ & ((1u << lii) - 1u)), pj = __popc(am_ & ((1u << lij) - 1u));
+              hv += T.c_J[k][0][pi] * T.c_JB[k][0][pj] + T.c_J[k][1][pi] * T.c_JB[k][1][pj] + T.c_J[k][2][pi] * T.c_JB[k][2][pj];
+            }
+          }
+          T.Lh[adr] = hv;
+        }
+      }
+      DM_SYNC();
+      factor(c, T.Lh, false, T.Lh, T.dinv_h);
+      // [ -g_f | H_fb ] through H_ff^-1, then the 3x3 Schur complement on the ball
+#pragma unroll
+      for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = make_float4(-g[s], hfb[s][0], hfb[s][1], hfb[s][2]);
+      DM_SYNC();
+      solve4(c, T.Lh, T.dinv_h);
+      float4 xs[4];
+      float sc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // S reductions: xx xy xz yy yz zz, rhs x y z
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        xs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot_on(c, s)) {
+          xs[s] = T.X4[c.sdof[s]];
+          sc[0] += hfb[s][0] * xs[s].y; sc[1] += hfb[s][0] * xs[s].z; sc[2] += hfb[s][0] * xs[s].w;
+          sc[3] += hfb[s][1] * xs[s].z; sc[4] += hfb[s][1] * xs[s].w; sc[5] += hfb[s][2] * xs[s].w;
+          sc[6] += hfb[s][0] * xs[s].x; sc[7] += hfb[s][1] * xs[s].x; sc[8] += hfb[s][2] * xs[s].x;
+        }
+      }
+      V3 db;
+      if (nc) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) sc[k] = wave_sum(sc[k]);
+        const float S00 = Hbb[0] - sc[0], S01 = Hbb[1] - sc[1], S02 = Hbb[2] - sc[2], S11 = Hbb[3] - sc[3], S12 = Hbb[4] - sc[4], S22 = Hbb[5] - sc[5];
+        const float r0 = -gb.x - sc[6], r1 = -gb.y - sc[7], r2 = -gb.z - sc[8];
+        // 3x3 symmetric solve (Cholesky)
+        const float l00 = sqrtf(S00), l10 = S01 / l00, l20 = S02 / l00, l11 = sqrtf(S11 - l10 * l10), l21 = (S12 - l20 * l10) / l11,
+                    l22 = sqrtf(S22 - l20 * l20 - l21 * l21);
+        const float y0 = r0 / l00, y1 = (r1 - l10 * y0) / l11, y2 = (r2 - l20 * y0 - l21 * y1) / l22;
+        db.z = y2 / l22; db.y = (y1 - l21 * db.z) / l11; db.x = (y0 - l10 * db.y - l20 * db.z) / l00;
+      } else db = (-1.f / Ib) * gb;
+      float dd[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) dd[s] = xs[s].x - xs[s].y * db.x - xs[s].z * db.y - xs[s].w * db.z;
+      // jd = J d per row; Md = -g - (H - M) d
+#pragma unroll
+      for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = dd[s];
+      DM_SYNC();
+      if (lane < nc) {
+        const int l = T.c_link[lane], nch = M.l_nchain[l];
+        float jd[3] = {0.f, 0.f, 0.f};
+        for (int p = 0; p < nch; p++) {
+          const float dv = T.X4[M.l_chain[p][l]].x;
+          jd[0] += T.c_J[lane][0][p] * dv; jd[1] += T.c_J[lane][1][p] * dv; jd[2] += T.c_J[lane][2][p] * dv;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) jd[r] += T.c_Jb[lane][r][0] * db.x + T.c_Jb[lane][r][1] * db.y + T.c_Jb[lane][r][2] * db.z;
+        const float *Hc = T.c_Hc[lane];
+        T.c_jd[lane][0] = jd[0]; T.c_jd[lane][1] = jd[1]; T.c_jd[lane][2] = jd[2];
+        T.c_w[lane][0] = Hc[0] * jd[0] + Hc[1] * jd[1] + Hc[2] * jd[2];
+        T.c_w[lane][1] = Hc[3] * jd[0] + Hc[4] * jd[1] + Hc[5] * jd[2];
+        T.c_w[lane][2] = Hc[6] * jd[0] + Hc[7] * jd[1] + Hc[8] * jd[2];
+      }
+      DM_SYNC();
+      float Md[4], c0s = 0.f, c1s = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        Md[s] = 0.f;
+        if (slot_on(c, s)) {
+          float md = -g[s] - hadd[s] * dd[s];
+          if (nc) md -= contact_gather(c, c.sblk[s], c.sli[s], T.c_w);
+          Md[s] = md;
+          c0s += (Ma[s] - qs[s]) * dd[s]; c1s += md * dd[s];
+        }
+      }
+      c0s = wave_sum(c0s) + dot(Ib * ab - qsb, db);
+      c1s = wave_sum(c1s) + Ib * dot(db, db);
+      // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(jar + alpha jd) jd
+      auto dphi = [&](float al) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (lsgn[s] != 0.f) {
+            const float jdv = lsgn[s] * dd[s], r = lsgn[s] * a[s] - laref[s] + al * jdv;
+            if (r < 0.f) acc += lD[s] * r * jdv;
+          }
+        }
+        if (lane < nc && !T.c_excl[lane]) {
+          float f0, f1, f2;
+          const float *jr = T.c_jar[lane], *jd = T.c_jd[lane];
+          cone_force(T.c_D[lane], T.c_mu[lane], jr[0] + al * jd[0], jr[1] + al * jd[1], jr[2] + al * jd[2], f0, f1, f2, nullptr);
+          acc -= f0 * jd[0] + f1 * jd[1] + f2 * jd[2];
+        }
+        return c0s + al * c1s + wave_sum(acc);
+      };
+      float alpha = 0.f;
+      {
+        const float d0 = dphi(0.f);
+        if (!(d0 < 0.f)) break;  // not a descent direction any more: converged to rounding
+        float lo = 0.f, hi = 1.f, dlo = d0, dhi = dphi(1.f);
+        int guard = 0;
+        while (dhi < 0.f && guard++ < 8) { lo = hi; dlo = dhi; hi *= 2.f; dhi = dphi(hi); }
+        if (dhi < 0.f) alpha = hi;
+        else {
+#pragma unroll 1
+          for (int ls = 0; ls < kLsIter; ls++) {
+            // regula falsi step safeguarded by bisection
+            float mid = lo - dlo * (hi - lo) / (dhi - dlo);
+            if (!(mid > lo + 0.05f * (hi - lo)) || !(mid < hi - 0.05f * (hi - lo))) mid = 0.5f * (lo + hi);
+            const float dm_ = dphi(mid);
+            if (dm_ < 0.f) { lo = mid; dlo = dm_; } else { hi = mid; dhi = dm_; }
+            if (fabsf(dm_) <= 1e-6f * fabsf(d0) || hi - lo <= 1e-6f * hi) break;
+          }
+          alpha = lo - dlo * (hi - lo) / (dhi - dlo);
+          if (!(alpha >= lo) || !(alpha <= hi)) alpha = 0.5f * (lo + hi);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; s++) { a[s] += alpha * dd[s]; Ma[s] += alpha * Md[s]; }
+      ab = ab + alpha * db;
+    }
+    // final forces at the solution
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
+    DM_SYNC();
+    if (lane < nc) {
+      const int l = T.c_link[lane], nch = M.l_nchain[l];
+      float jar[3] = {-T.c_aref[lane][0], -T.c_aref[lane][1], -T.c_aref[lane][2]};
+      for (int p = 0; p < nch; p++) {
+        const float av = T.X4[M.l_chain[p][l]].x;
+        jar[0] += T.c_J[lane][0][p] * av; jar[1] += T.c_J[lane][1][p] * av; jar[2] += T.c_J[lane][2][p] * av;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[lane][r][0] * ab.x + T.c_Jb[lane][r][1] * ab.y + T.c_Jb[lane][r][2] * ab.z;
+      float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+      if (!T.c_excl[lane]) cone_force(T.c_D[lane], T.c_mu[lane], jar[0], jar[1], jar[2], f0, f1, f2, nullptr);
+      T.c_f[lane][0] = f0; T.c_f[lane][1] = f1; T.c_f[lane][2] = f2;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      lf[s] = 0.f;
+      if (lsgn[s] != 0.f) { const float r = lsgn[s] * a[s] - laref[s]; if (r < 0.f) lf[s] = -lD[s] * r; }
+    }
+    DM_SYNC();
+  } else {
+    for (int k = lane; k < nc * 3; k += 64) T.c_f[k / 3][k % 3] = 0.f;
+    DM_SYNC();
+  }
+  iters_out += iters;
+  // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
+  //      unregularised A = J M^-1 J'; everything else (normal and limit forces) enters through w0 = M^-1 J' f_other
+  bool did_noslip = false;
+  if (nact > 0 && M.noslip_iterations > 0 && !(c.flags & BF_NO_NOSLIP)) {
+    did_noslip = true;
+    const int nr = 2 * nc;
+    // w0
+    for (int k = lane; k < nc; k += 64) { T.c_w[k][0] = T.c_f[k][0]; T.c_w[k][1] = 0.f; T.c_w[k][2] = 0.f; }
+    DM_SYNC();
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      if (slot_on(c, s)) {
+        float f = lsgn[s] * lf[s] + contact_gather(c, c.sblk[s], c.sli[s], T.c_w);
+        T.X4[c.sdof[s]] = make_float4(f, 0.f, 0.f, 0.f);
+      }
+    }
+    V3 w0b = {0.f, 0.f, 0.f};
+    for (int k = 0; k < nc; k++) {
+      w0b.x += T.c_Jb[k][0][0] * T.c_f[k][0]; w0b.y += T.c_Jb[k][0][1] * T.c_f[k][0]; w0b.z += T.c_Jb[k][0][2] * T.c_f[k][0];
+    }
+    w0b = (1.f / Ib) * w0b;
+    DM_SYNC();
+    solve4(c, T.Lm, T.dinv_m);
+    float w0[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) w0[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
+    // b' = J_t (a_smooth + w0) - aref_t  (lane = tangential row)
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = am[s] + w0[s];
+    DM_SYNC();
+    float brow = 0.f;
+    if (lane < nr) {
+      const int k = lane >> 1, r = 1 + (lane & 1), l = T.c_link[k], nch = M.l_nchain[l];
+      float sacc = -T.c_aref[k][r];
+      for (int p = 0; p < nch; p++) sacc += T.c_J[k][r][p] * T.X4[M.l_chain[p][l]].x;
+      const V3 ub = amb + w0b;
+      sacc += T.c_Jb[k][r][0] * ub.x + T.c_Jb[k][r][1] * ub.y + T.c_Jb[k][r][2] * ub.z;
+      brow = sacc;
+    }
+    DM_SYNC();
+    // A_tt, four columns per solve
+    float arow[2 * NC];
+#pragma unroll
+    for (int k = 0; k < 2 * NC; k++) arow[k] = 0.f;
+#pragma unroll 1
+    for (int base = 0; base < nr; base += 4) {
+      for (int f = lane; f < ND; f += 64) T.X4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      DM_SYNC();
+      for (int item = lane; item < 4 * NCH; item += 64) {
+        const int col = item / NCH, p = item - col * NCH, row = base + col;
+        if (row < nr) {
+          const int k = row >> 1, r = 1 + (row & 1), l = T.c_link[k], f = M.l_chain[p][l];
+          if (f >= 0) (&T.X4[f].x)[col] = T.c_J[k][r][p];
+        }
+      }
+      DM_SYNC();
+      solve4(c, T.Lm, T.dinv_m);
+      if (lane < nr) {
+        const int k = lane >> 1, r = 1 + (lane & 1), l = T.c_link[k], nch = M.l_nchain[l];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < nch; p++) {
+          const float jv = T.c_J[k][r][p];
+          const float4 y = T.X4[M.l_chain[p][l]];
+          acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
+        }
+#pragma unroll
+        for (int col = 0; col < 4; col++) {
+          const int row = base + col;
+          if (row < nr) {
+            const int k2 = row >> 1, r2 = 1 + (row & 1);
+            const float ball = (T.c_Jb[k][r][0] * T.c_Jb[k2][r2][0] + T.c_Jb[k][r][1] * T.c_Jb[k2][r2][1] + T.c_Jb[k][r][2] * T.c_Jb[k2][r2][2]) / Ib;
+            const float val = (col == 0 ? acc.x : (col == 1 ? acc.y : (col == 2 ? acc.z : acc.w))) + ball;
+#pragma unroll
+            for (int q2 = 0; q2 < 2 * NC; q2++) if (q2 == row) arow[q2] = val;
+          }
+        }
+      }
+      DM_SYNC();
+    }
+    // stage A, b, f in LDS (aliases the link-exchange buffer, idle here), then sweep
+    if (lane < nr) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2 * NC; q2++) T.ns.A[lane][q2] = arow[q2];
+      T.ns.b[lane] = brow;
+      T.ns.f[lane] = T.c_f[lane >> 1][1 + (lane & 1)];
+    }
+    DM_SYNC();
+    const float scale = 1.f / (M.meaninertia * 105.f);
+    for (int iter = 0; iter < M.noslip_iterations; iter++) {
+      float improvement = 0.f;
+      for (int k = 0; k < nc; k++) {
+        if (T.c_excl[k]) continue;
+        const int r0 = 2 * k, r1 = 2 * k + 1;
+        float res0 = T.ns.b[r0], res1 = T.ns.b[r1];
+        for (int q2 = 0; q2 < nr; q2++) { const float fv = T.ns.f[q2]; res0 += T.ns.A[r0][q2] * fv; res1 += T.ns.A[r1][q2] * fv; }
+        const float o0 = T.ns.f[r0], o1 = T.ns.f[r1];
+        const float A00 = T.ns.A[r0][r0], A01 = T.ns.A[r0][r1], A11 = T.ns.A[r1][r1];
+        const float fn = T.c_f[k][0];
+        float v0 = 0.f, v1 = 0.f;
+        if (fn >= 1e-15f) {
+          const float b0 = res0 - A00 * o0 - A01 * o1, b1 = res1 - A01 * o0 - A11 * o1, mu = T.c_mu[k];
+          const bool active = qcqp2(v0, v1, A00, A01, A11, b0, b1, mu, fn);
+          if (active) {
+            const float ssum = (v0 * v0 + v1 * v1) / (mu * mu);
+            const float sc2 = sqrtf(fn * fn / fmaxf(1e-15f, ssum));
+            v0 *= sc2; v1 *= sc2;
+          }
+        }
+        const float d0 = v0 - o0, d1 = v1 - o1;
+        float change = d0 * res0 + d1 * res1 + 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1));
+        if (change > 1e-10f) { v0 = o0; v1 = o1; change = 0.f; }
+        improvement -= change;
+        DM_SYNC();
+        if (lane == 0) { T.ns.f[r0] = v0; T.ns.f[r1] = v1; }
+        DM_SYNC();
+      }
+      if (improvement * scale < 1e-6f) break;
+    }
+    if (lane < nr) T.c_f[lane >> 1][1 + (lane & 1)] = T.ns.f[lane];
+    DM_SYNC();
+  }
+  // ---- constraint forces in joint space, final acceleration
+  float qc[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    qc[s] = 0.f;
+    if (slot_on(c, s)) {
+      qc[s] = lsgn[s] * lf[s];
+      if (nc) qc[s] += contact_gather(c, c.sblk[s], c.sli[s], T.c_f);
+    }
+  }
+  V3 qcb = {0.f, 0.f, 0.f};
+  for (int k = 0; k < nc; k++) {
+    const float f0 = T.c_f[k][0], f1 = T.c_f[k][1], f2 = T.c_f[k][2];
+    qcb.x += T.c_Jb[k][0][0] * f0 + T.c_Jb[k][1][0] * f1 + T.c_Jb[k][2][0] * f2;
+    qcb.y += T.c_Jb[k][0][1] * f0 + T.c_Jb[k][1][1] * f1 + T.c_Jb[k][2][1] * f2;
+    qcb.z += T.c_Jb[k][0][2] * f0 + T.c_Jb[k][1][2] * f1 + T.c_Jb[k][2][2] * f2;
+  }
+  // Euler with implicit joint damping (mj: mj_Euler): (M + h B) qacc_e = qfrc_smooth + qfrc_constraint; with noslip the
+  // unconstrained-metric acceleration qacc = a_s + M^-1 J' f rides along as a second right-hand side
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    if (slot_on(c, s)) {
+      T.dadd[c.sdof[s]] = (c.flags & BF_NO_DAMPER) ? 0.f : h * c.damp[s];
+      T.X4[c.sdof[s]] = make_float4(qs[s] + qc[s], 0.f, 0.f, 0.f);
+    }
+  }
+  DM_SYNC();
+  float qacc[4];
+  if (did_noslip) {
+    float4 keep[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) keep[s] = slot_on(c, s) ? T.X4[c.sdof[s]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = qc[s];
+    DM_SYNC();
+    solve4(c, T.Lm, T.dinv_m);
+#pragma unroll
+    for (int s = 0; s < 4; s++) { a[s] = slot_on(c, s) ? am[s] + T.X4[c.sdof[s]].x : 0.f; }
+    ab = amb + (1.f / Ib) * qcb;
+    DM_SYNC();
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = keep[s];
+    DM_SYNC();
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++) qacc[s] = a[s];
+  {
+    float n2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (slot_on(c, s)) n2 += qacc[s] * qacc[s];
+    *qacc_norm2 = wave_sum(n2) + dot(ab, ab);
+  }
+  // ---- sensors (mj: mj_rnePostConstraint + mj_sensorAcc): touch = normal force on the claw, force = interaction
+  //      force on the tarsus from its parent, in the tarsus site frame
+  {
+    V3 fext = {0.f, 0.f, 0.f};
+    float touch = 0.f;
+    for (int k = 0; k < nc; k++) {
+      if (T.c_link[k] == lane && !T.c_excl[k]) {
+        const float *fr = T.c_frame[k];
+        const float f0 = T.c_f[k][0], f1 = T.c_f[k][1], f2 = T.c_f[k][2];
+        fext = fext + V3{fr[0] * f0 + fr[3] * f1 + fr[6] * f2, fr[1] * f0 + fr[4] * f1 + fr[7] * f2, fr[2] * f0 + fr[5] * f1 + fr[8] * f2};
+        if (f0 > 0.f) touch += f0;
+      }
+    }
+    S6 cacc2 = zero6();
+#pragma unroll 1
+    for (int d = 1; d <= M.maxdepth; d++) {
+      if (c.depth == d) {
+        S6 pa = {0.f, 0.f, 0.f, 0.f, 0.f, (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz};
+        if (c.parent >= 0) pa = ld6(T.lk[c.parent]);
+#pragma unroll
+        for (int s = 0; s < 3; s++) if (s < c.ndof) pa = pa + c.v[s] * c.cdd[s] + qacc[s] * c.cdof[s];
+        cacc2 = pa;
+        st6(T.lk[lane], pa);
+      }
+      DM_SYNC();
+    }
+    const S6 t1 = mul_inert(c.cinert, cacc2), t2 = mul_inert(c.cinert, c.cvel);
+    V3 fint = lin(t1) + lin(cross_force(c.cvel, t2)) - fext;
+#pragma unroll 1
+    for (int d = M.maxdepth; d >= 1; d--) {
+      if (c.depth == d) {
+        if (c.nchild > 0) { const float *p = T.lk[c.ch0]; fint = fint + V3{p[0], p[1], p[2]}; }
+        if (c.nchild > 1) { const float *p = T.lk[c.ch1]; fint = fint + V3{p[0], p[1], p[2]}; }
+        if (c.nchild > 2) { const float *p = T.lk[c.ch2]; fint = fint + V3{p[0], p[1], p[2]}; }
+        float *o = T.lk[lane];
+        o[0] = fint.x; o[1] = fint.y; o[2] = fint.z;
+      }
+      DM_SYNC();
+    }
+    if (M.l_force[lane] >= 0) {
+      const Q4 sq = qmul(c.xq, Q4{M.l_fsite[0][lane], M.l_fsite[1][lane], M.l_fsite[2][lane], M.l_fsite[3][lane]});
+      const V3 fl_ = mtv(q2m(sq), fint);
+      const int o = 3 * M.l_force[lane];
+      T.sens[o] += fl_.x; T.sens[o + 1] += fl_.y; T.sens[o + 2] += fl_.z;
+    }
+    if (M.l_touch[lane] >= 0) T.sens[18 + M.l_touch[lane]] += touch;
+    DM_SYNC();
+  }
+  if (!integrate) return;  // mj_forward: state untouched
+  // ---- integrate
+  bool any_damp = false;
+#pragma unroll
+  for (int s = 0; s < 4; s++) any_damp |= slot_on(c, s) && c.damp[s] > 0.f && !(c.flags & BF_NO_DAMPER);
+  float qe[4];
+  if (__any(any_damp)) {
+    factor(c, T.Mq, true, T.Lh, T.dinv_h);
+    solve4(c, T.Lh, T.dinv_h);
+#pragma unroll
+    for (int s = 0; s < 4; s++) qe[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; s++) qe[s] = qacc[s];
+  }
+  DM_SYNC();
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    if (slot_on(c, s)) { c.v[s] += h * qe[s]; c.q[s] += h * c.v[s]; }
+  }
+  // ball: no damping, so its Euler acceleration is ab = (tau_smooth + J_b' f) / I
+  c.bw = c.bw + h * ab;
+  {
+    const float wn = sqrtf(dot(c.bw, c.bw));
+    if (wn >= 1e-15f) {
+      const Q4 dq = axis_angle((1.f / wn) * c.bw, wn * h);
+      c.bq = qnormalize(qmul(qnormalize(c.bq), dq));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel
+__global__ __launch_bounds__(64, 1) void ball_step_kernel(const BallModel *__restrict__ Mp, BTaskDev K, BState *__restrict__ states,
+                                                         const float *__restrict__ act, float *__restrict__ obs, float *__restrict__ rew,
+                                                         float *__restrict__ disc, int *__restrict__ st, int batch, int mode, int nphys) {
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= batch) return;
+  __shared__ BTile T;
+  const BallModel &M = *Mp;
+  BState &S = states[env];
+  Ctx c;
+  c.M = Mp; c.T = &T; c.lane = lane; c.flags = K.flags;
+  c.parent = M.l_parent[lane]; c.depth = M.l_depth[lane]; c.nchild = M.l_nchild[lane];
+  c.ch0 = M.l_child[0][lane]; c.ch1 = M.l_child[1][lane]; c.ch2 = M.l_child[2][lane]; c.ndof = M.l_ndof[lane];
+  c.pos = {M.l_pos[0][lane], M.l_pos[1][lane], M.l_pos[2][lane]};
+  c.quat = {M.l_quat[0][lane], M.l_quat[1][lane], M.l_quat[2][lane], M.l_quat[3][lane]};
+  c.ipos = {M.l_ipos[0][lane], M.l_ipos[1][lane], M.l_ipos[2][lane]};
+  c.iquat = {M.l_iquat[0][lane], M.l_iquat[1][lane], M.l_iquat[2][lane], M.l_iquat[3][lane]};
+  c.inertia = {M.l_inertia[0][lane], M.l_inertia[1][lane], M.l_inertia[2][lane]};
+  c.mass = M.l_mass[lane];
+#pragma unroll
+  for (int k = 0; k < 8; k++) c.fl[k] = M.l_fl[k][lane];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int f = M.s_dof[s][lane];
+    c.sdof[s] = f;
+    c.sblk[s] = f >= 0 ? M.d_blk[f] : 0; c.sli[s] = f >= 0 ? M.d_li[f] : 0; c.slim[s] = M.s_limited[s][lane];
+    c.stiff[s] = M.s_stiff[s][lane]; c.sref[s] = M.s_sref[s][lane]; c.damp[s] = M.s_damp[s][lane];
+    c.lo[s] = M.s_lo[s][lane]; c.hi[s] = M.s_hi[s][lane]; c.invw[s] = M.s_invw[s][lane]; c.sK[s] = M.s_K[s][lane]; c.sB[s] = M.s_B[s][lane];
+  }
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    c.axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
+    c.jpos[s] = {M.s_jpos[0][s][lane], M.s_jpos[1][s][lane], M.s_jpos[2][s][lane]};
+  }
+#pragma unroll
+  for (int t = 0; t < ECAP; t++) {
+    c.emeta[t] = M.e_meta[t][lane];
+    c.eadr[t] = (unsigned)M.e_adr[t][lane] | ((unsigned)M.e_fmask[t][lane] << 16);
+    const unsigned i = c.emeta[t] & 0xffu;
+    c.estep[t] = (unsigned)M.e_rowstep[t][lane] | ((unsigned)M.e_colstep[t][lane] << 8) | ((unsigned)(unsigned short)M.d_madr[i < ND ? i : 0] << 16);
+  }
+  const bool do_reset = (mode == 1) || (mode == 0 && S.needs_reset != 0);
+  const bool phys_only = (mode == 2);
+  float act_reg = 0.f, ctrl_reg = 0.f;
+  int step_counter = S.step_counter, iters = 0;
+  if (do_reset) {
+    // ref: walk_on_ball.py:52-54 + fruitfly.py:330-340: qpos0, zero velocity / activation, wings folded to their spring reference
+#pragma unroll
+    for (int s = 0; s < 4; s++) { c.q[s] = 0.f; c.v[s] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+      if (slot_on(c, s)) for (int w = 0; w < M.nwing; w++) if (M.wing_dof[w] == c.sdof[s]) c.q[s] = M.qspring[c.sdof[s]];
+    c.bq = {1.f, 0.f, 0.f, 0.f}; c.bw = {0.f, 0.f, 0.f};
+    step_counter = 0;
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; s++) { c.q[s] = slot_on(c, s) ? S.q[c.sdof[s]] : 0.f; c.v[s] = slot_on(c, s) ? S.v[c.sdof[s]] : 0.f; }
+    c.bq = {S.ballq[0], S.ballq[1], S.ballq[2], S.ballq[3]}; c.bw = {S.ballw[0], S.ballw[1], S.ballw[2]};
+    act_reg = lane < NU ? S.act[lane] : 0.f;
+    if (lane < NU) {
+      if (phys_only) ctrl_reg = act[(size_t)env * NU + lane];
+      else {
+        // ref: fruitfly.py:480-492 apply_action (+ the CanonicalSpecWrapper the reference wraps every env in)
+        const int ai = M.a_action[lane];
+        float av = ai >= 0 ? act[(size_t)env * NACT + ai] : 0.f;
+        if (!(av == av)) av = 0.f;
+        if (K.canonical && ai >= 0) {
+          if (K.clip) av = fminf(fmaxf(av, -1.f), 1.f);
+          av = M.act_lo[ai] + 0.5f * (av + 1.f) * (M.act_hi[ai] - M.act_lo[ai]);
+        }
+        ctrl_reg = av;
+      }
+    }
+    if (!phys_only) step_counter++;
+  }
+  if (lane < 32) T.sens[lane] = 0.f;
+  DM_SYNC();
+  const int nsub = phys_only ? nphys : M.nsub;
+  float qn2 = 0.f;
+  stage1(c);
+  if (do_reset) {
+    // mj_forward after the reset with actuation disabled (dm_control's after_reset); its sensors are the first sample
+    float dummy;
+    const int saved = c.flags;
+    c.flags |= BF_NO_ACTUATION;
+    stage2(c, 0.f, 0.f, dummy, false, iters, &qn2);
+    c.flags = saved;
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < nsub; s++) {
+      float act_new;
+      stage2(c, act_reg, ctrl_reg, act_new, true, iters, &qn2);
+      act_reg = act_new;
+      stage1(c);
+    }
+  }
+  // ---- store state
+#pragma unroll
+  for (int s = 0; s < 4; s++) if (slot_on(c, s)) { S.q[c.sdof[s]] = c.q[s]; S.v[c.sdof[s]] = c.v[s]; }
+  if (lane < NU) S.act[lane] = do_reset ? 0.f : act_reg;
+  if (lane == 0) {
+    S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
+    S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
+    S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc;
+  }
+  if (phys_only) return;
+  // ---- observation (ref: SURVEY App. A order): accelerometer 3 | actuator_activation 59 | appendages_pos 21 | ball_qvel 3 |
+  //      force 18 | gyro 3 | joints_pos 85 | joints_vel 85 | touch 6 | velocimeter 3 | world_zaxis 3
+#pragma unroll
+  for (int s = 0; s < 4; s++) if (slot_on(c, s)) { T.Q[c.sdof[s]] = c.q[s]; T.V[c.sdof[s]] = c.v[s]; }
+  {
+    float *o = T.lk[lane];
+    o[0] = c.xp.x; o[1] = c.xp.y; o[2] = c.xp.z; o[3] = c.xq.w; o[4] = c.xq.x; o[5] = c.xq.y; o[6] = c.xq.z;
+  }
+  DM_SYNC();
+  float *ob = obs + (size_t)env * NOBS;
+  const float inv = (do_reset && K.pad_first_obs) ? 1.f : 1.f / (float)M.nsub;
+  const int nsamp = do_reset ? 1 : M.nsub;
+  const M3 Rt = q2m(Q4{M.thorax_quat[0], M.thorax_quat[1], M.thorax_quat[2], M.thorax_quat[3]});
+  const M3 Rs = q2m(Q4{M.site_quat[0], M.site_quat[1], M.site_quat[2], M.site_quat[3]});
+  if (lane < 3) {
+    // the thorax is welded to the world: accelerometer = R_site' (0, 0, -g), gyro = velocimeter = 0
+    const V3 g = mtv(Rs, V3{0.f, 0.f, (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz});
+    ob[lane] = (lane == 0 ? g.x : (lane == 1 ? g.y : g.z)) * (float)nsamp * inv;
+    ob[3 + NU + 21 + 3 + 18 + lane] = 0.f;                       // gyro
+    ob[3 + NU + 21 + 3 + 18 + 3 + 2 * NOBSJ + 6 + lane] = 0.f;   // velocimeter
+    ob[3 + NU + 21 + 3 + 18 + 3 + 2 * NOBSJ + 6 + 3 + lane] = lane == 0 ? Rt.m6 : (lane == 1 ? Rt.m7 : Rt.m8);  // world_zaxis = xmat[6:9]
+    ob[3 + NU + 21 + lane] = lane == 0 ? c.bw.x : (lane == 1 ? c.bw.y : c.bw.z);  // ball_qvel
+  }
+  if (lane < NU) ob[3 + lane] = do_reset ? 0.f : act_reg;
+  if (lane < 7) {  // appendages_pos: (x_site - x_thorax) . R_thorax (ref: fruitfly.py:629-638)
+    const int l = M.app_link[lane];
+    const float *p = T.lk[l];
+    const V3 sp = V3{p[0], p[1], p[2]} + qrot(Q4{p[3], p[4], p[5], p[6]}, V3{M.app_pos[lane][0], M.app_pos[lane][1], M.app_pos[lane][2]});
+    const V3 rel = mtv(Rt, sp - V3{M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]});
+    ob[3 + NU + 3 * lane] = rel.x; ob[3 + NU + 3 * lane + 1] = rel.y; ob[3 + NU + 3 * lane + 2] = rel.z;
+  }
+  if (lane < 18) ob[3 + NU + 21 + 3 + lane] = T.sens[lane] * inv;
+  if (lane < 6) ob[3 + NU + 21 + 3 + 18 + 3 + 2 * NOBSJ + lane] = T.sens[18 + lane] * inv;
+  for (int k = lane; k < NOBSJ; k += 64) {
+    ob[3 + NU + 21 + 3 + 18 + 3 + k] = T.Q[M.obs_dof[k]];
+    ob[3 + NU + 21 + 3 + 18 + 3 + NOBSJ + k] = T.V[M.obs_dof[k]];
+  }
+  // ---- reward / termination (ref: walk_on_ball.py:61-79, base.py:213-217)
+  if (lane == 0) {
+    if (do_reset) { rew[env] = 0.f; disc[env] = 1.f; st[env] = 0; S.needs_reset = 0; }
+    else {
+      float r = fmaxf(0.f, 1.f - fabsf(c.bw.x) / 6.f) * fmaxf(0.f, 1.f - fabsf(c.bw.y + 5.f) / 6.f) * fmaxf(0.f, 1.f - fabsf(c.bw.z) / 6.f);
+      const bool bad = !(qn2 == qn2) || !(sqrtf(qn2) <= 1e14f);
+      const bool timeup = step_counter >= K.time_limit_steps;
+      if (bad && !(r == r)) r = 0.f;
+      rew[env] = r; disc[env] = bad ? 0.f : 1.f; st[env] = (bad || timeup) ? 2 : 1;
+      S.needs_reset = (bad || timeup) ? 1 : 0;
+    }
+  }
+}
+
+__global__ void ball_init_states(BState *states, int batch) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  BState z;
+  memset(&z, 0, sizeof(z));
+  z.needs_reset = 1; z.ballq[0] = 1.f;
+  states[i] = z;
+}
+__global__ void ball_get_state_kernel(const BState *states, double *qpos, double *qvel, int batch) {
+  const int env = blockIdx.x, t = threadIdx.x;
+  if (env >= batch) return;
+  const BState &S = states[env];
+  for (int k = t; k < 106; k += blockDim.x) qpos[(size_t)env * 106 + k] = k < 4 ? (double)S.ballq[k] : (double)S.q[k - 4];
+  for (int k = t; k < 105; k += blockDim.x) qvel[(size_t)env * 105 + k] = k < 3 ? (double)S.ballw[k] : (double)S.v[k - 3];
+}
+__global__ void ball_set_state_kernel(BState *states, const double *qpos, const double *qvel, int batch) {
+  const int env = blockIdx.x, t = threadIdx.x;
+  if (env >= batch) return;
+  BState &S = states[env];
+  for (int k = t; k < 106; k += blockDim.x) { if (k < 4) S.ballq[k] = (float)qpos[(size_t)env * 106 + k]; else S.q[k - 4] = (float)qpos[(size_t)env * 106 + k]; }
+  for (int k = t; k < 105; k += blockDim.x) { if (k < 3) S.ballw[k] = (float)qvel[(size_t)env * 105 + k]; else S.v[k - 3] = (float)qvel[(size_t)env * 105 + k]; }
+}
+__global__ void ball_act_kernel(BState *states, double *act, int batch, int set) {
+  const int env = blockIdx.x, t = threadIdx.x;
+  if (env >= batch || t >= NU) return;
+  if (set) states[env].act[t] = (float)act[(size_t)env * NU + t];
+  else act[(size_t)env * NU + t] = (double)states[env].act[t];
+}
+__global__ void ball_task_state_kernel(const BState *states, int *ints, double *reals, int batch) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  const BState &S = states[i];
+  int *o = ints + (size_t)i * 8;
+  o[0] = 0; o[1] = 0; o[2] = S.step_counter; o[3] = 0; o[4] = S.needs_reset; o[5] = S.ncon; o[6] = S.iters; o[7] = S.overflow;
+  for (int k = 0; k < 8; k++) reals[(size_t)i * 8 + k] = 0.0;
+}
+
+// ================================================================================================ host side
+#define HIPB_OK(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct BallEnv {
+  int device = 0, batch = 0;
+  BallHost host;
+  BTaskDev task{};
+  BallModel *model_dev = nullptr;
+  BState *states = nullptr;
+  double control_timestep = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+BallEnv *ball_create(const void *blob, size_t blob_size, const BallTaskHost &task, int batch, int device) {
+  if (!blob || batch <= 0) throw std::runtime_error("ffe_create_walk_on_ball: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device: the MI355X path has no CPU fallback");
+  HIPB_OK(hipSetDevice(device));
+  std::unique_ptr<BallEnv> e(new BallEnv());
+  Blob b(blob, blob_size);
+  e->host = build_ball_model(b);
+  e->device = device; e->batch = batch;
+  e->control_timestep = task.control_timestep;
+  e->host.m.nsub = (int)llround(task.control_timestep / (double)e->host.m.h);
+  if (e->host.m.nsub < 1 || e->host.m.nsub > 64) throw std::runtime_error("walk_on_ball: bad control timestep");
+  e->task.time_limit_steps = task.time_limit_steps; e->task.pad_first_obs = task.pad_first_obs; e->task.flags = task.physics_flags;
+  e->task.canonical = task.canonical_actions; e->task.clip = task.clip_actions;
+  HIPB_OK(hipMalloc((void **)&e->model_dev, sizeof(BallModel)));
+  HIPB_OK(hipMemcpy(e->model_dev, &e->host.m, sizeof(BallModel), hipMemcpyHostToDevice));
+  HIPB_OK(hipMalloc((void **)&e->states, sizeof(BState) * (size_t)batch));
+  hipLaunchKernelGGL(ball_init_states, dim3((batch + 63) / 64), dim3(64), 0, 0, e->states, batch);
+  HIPB_OK(hipGetLastError());
+  HIPB_OK(hipDeviceSynchronize());
+  HIPB_OK(hipEventCreate(&e->ev0));
+  HIPB_OK(hipEventCreate(&e->ev1));
+  return e.release();
+}
+void ball_destroy(BallEnv *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->model_dev) (void)hipFree(e->model_dev);
+  if (e->states) (void)hipFree(e->states);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  delete e;
+}
+void ball_spec(const BallEnv *e, int *nq, int *nv, int *nu, int *action_dim, int *obs_dim, int *nsub, double *h, double *ctrl_dt) {
+  *nq = 106; *nv = 105; *nu = NU; *action_dim = NACT; *obs_dim = NOBS; *nsub = e->host.m.nsub; *h = e->host.m.h; *ctrl_dt = e->control_timestep;
+}
+void ball_action_bounds(const BallEnv *e, float *mn, float *mx) {
+  for (int k = 0; k < NACT; k++) { mn[k] = e->host.action_min[k]; mx[k] = e->host.action_max[k]; }
+}
+void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys) {
+  if (mode != 1 && !act) throw std::runtime_error("walk_on_ball: null action buffer");
+  if (mode != 2 && (!obs || !rew || !disc || !st)) throw std::runtime_error("walk_on_ball: null output buffer");
+  hipLaunchKernelGGL(ball_step_kernel, dim3(e->batch), dim3(64), 0, (hipStream_t)stream, e->model_dev, e->task, e->states, act, obs, rew, disc, st,
+                     e->batch, mode, nphys);
+  HIPB_OK(hipGetLastError());
+}
+void ball_get_state(BallEnv *e, double *qpos, double *qvel, void *stream) {
+  hipLaunchKernelGGL(ball_get_state_kernel, dim3(e->batch), dim3(128), 0, (hipStream_t)stream, e->states, qpos, qvel, e->batch);
+  HIPB_OK(hipGetLastError());
+}
+void ball_set_state(BallEnv *e, const double *qpos, const double *qvel, void *stream) {
+  hipLaunchKernelGGL(ball_set_state_kernel, dim3(e->batch), dim3(128), 0, (hipStream_t)stream, e->states, qpos, qvel, e->batch);
+  HIPB_OK(hipGetLastError());
+}
+void ball_get_act(BallEnv *e, double *act, void *stream) {
+  hipLaunchKernelGGL(ball_act_kernel, dim3(e->batch), dim3(64), 0, (hipStream_t)stream, e->states, act, e->batch, 0);
+  HIPB_OK(hipGetLastError());
+}
+void ball_set_act(BallEnv *e, const double *act, void *stream) {
+  hipLaunchKernelGGL(ball_act_kernel, dim3(e->batch), dim3(64), 0, (hipStream_t)stream, e->states, const_cast<double *>(act), e->batch, 1);
+  HIPB_OK(hipGetLastError());
+}
+void ball_get_task_state(BallEnv *e, int32_t *ints, double *reals, void *stream) {
+  hipLaunchKernelGGL(ball_task_state_kernel, dim3((e->batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->states, ints, reals, e->batch);
+  HIPB_OK(hipGetLastError());
+}
+float ball_time_steps(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  HIPB_OK(hipEventRecord(e->ev0, s));
+  for (int k = 0; k < iters; k++) ball_launch(e, act, obs, rew, disc, st, stream, 0, 0);
+  HIPB_OK(hipEventRecord(e->ev1, s));
+  HIPB_OK(hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIPB_OK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  return ms / (float)iters;
+}
+
+}  // namespace ffb

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/flybody_env.h"
+#include "ball_env.hpp"
 #include "dev_model.hpp"
 
 #ifndef FFE_WAVES_PER_SIMD
@@ -1418,6 +1419,7 @@ __global__ void test_quat_kernel(int op, const float *a, const float *b, float *
 using namespace ffe;
 
 struct ffe_env {
+  ffb::BallEnv *ball = nullptr;  // walk_on_ball handles dispatch to ball_env.hip; everything below is the flight env
   int device = 0, batch = 0;
   DevModel dm{};
   TaskDev task{};
@@ -1448,7 +1450,39 @@ static T *upload(ffe_env *h, const T *src, size_t n) {
   return p;
 }
 
+// walk_on_ball handles: run `body` on the ball env, translating exceptions into the ABI's error codes
+#define FFE_BALL_DISPATCH(h, body)                                    \
+  if ((h) && (h)->ball) {                                             \
+    try { body; } catch (const std::exception &e_) { (h)->err = e_.what(); return -2; } \
+    return 0;                                                         \
+  }
+
 extern "C" {
+
+int ffe_create_walk_on_ball(const void *model_blob, size_t blob_size, const ffe_ball_task *task, int batch, int device, ffe_handle *out) {
+  if (!out) return -1;
+  *out = nullptr;
+  std::unique_ptr<ffe_env> h(new ffe_env());
+  try {
+    if (!task) throw std::runtime_error("ffe_create_walk_on_ball: bad arguments");
+    ffb::BallTaskHost t{task->time_limit_steps, task->pad_first_obs, task->physics_flags, task->canonical_actions, task->clip_actions,
+                        task->control_timestep};
+    h->ball = ffb::ball_create(model_blob, blob_size, t, batch, device);
+    h->device = device; h->batch = batch;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+  *out = h.release();
+  return 0;
+}
+int ffe_get_act(ffe_handle h, double *act_dev, void *stream) {
+  if (!h || !act_dev || !h->ball) return -1;
+  FFE_BALL_DISPATCH(h, ffb::ball_get_act(h->ball, act_dev, stream));
+  return -1;
+}
+int ffe_set_act(ffe_handle h, const double *act_dev, void *stream) {
+  if (!h || !act_dev || !h->ball) return -1;
+  FFE_BALL_DISPATCH(h, ffb::ball_set_act(h->ball, act_dev, stream));
+  return -1;
+}
 
 const char *ffe_version(void) { return "flybody_amd 0.1 (gfx950, wave-per-env)"; }
 const char *ffe_last_error(ffe_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
@@ -1517,6 +1551,7 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
 
 int ffe_destroy(ffe_handle h) {
   if (!h) return -1;
+  if (h->ball) { ffb::ball_destroy(h->ball); delete h; return 0; }
   (void)hipSetDevice(h->device);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1527,6 +1562,16 @@ int ffe_destroy(ffe_handle h) {
 
 int ffe_spec(ffe_handle h, ffe_spec_t *s) {
   if (!h || !s) return -1;
+  if (h->ball) {
+    std::memset(s, 0, sizeof(*s));
+    ffb::ball_spec(h->ball, &s->nq, &s->nv, &s->nu, &s->action_dim, &s->obs_dim, &s->nsub, &s->physics_timestep, &s->control_timestep);
+    s->batch = h->batch;
+    // walk_on_ball row: accelerometer 3 | actuator_activation 59 | appendages_pos 21 | ball_qvel 3 | force 18 | gyro 3 |
+    //                   joints_pos 85 | joints_vel 85 | touch 6 | velocimeter 3 | world_zaxis 3
+    s->off_accelerometer = 0; s->off_gyro = 104; s->off_joints_pos = 107; s->off_joints_vel = 192; s->off_velocimeter = 283; s->off_world_zaxis = 286;
+    s->off_ref_displacement = -1; s->off_ref_root_quat = -1; s->n_obs_joints = 85; s->n_ref = 0;
+    return 0;
+  }
   const DevModel &M = h->dm;
   const int nref = h->task.future_steps + 1, nj = M.nobsj;
   s->batch = h->batch; s->nq = M.nq; s->nv = M.nv; s->nu = M.nu; s->action_dim = M.naction; s->obs_dim = h->task.obs_dim; s->nsub = M.nsub;
@@ -1539,6 +1584,7 @@ int ffe_spec(ffe_handle h, ffe_spec_t *s) {
 
 int ffe_action_bounds(ffe_handle h, float *mn, float *mx) {
   if (!h || !mn || !mx) return -1;
+  FFE_BALL_DISPATCH(h, ffb::ball_action_bounds(h->ball, mn, mx));
   std::memcpy(mn, h->host.action_min.data(), h->host.action_min.size() * sizeof(float));
   std::memcpy(mx, h->host.action_max.data(), h->host.action_max.size() * sizeof(float));
   return 0;
@@ -1546,6 +1592,7 @@ int ffe_action_bounds(ffe_handle h, float *mn, float *mx) {
 
 static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys = 0) {
   if (!h) return -1;
+  FFE_BALL_DISPATCH(h, ffb::ball_launch(h->ball, act, obs, rew, disc, st, stream, mode, nphys));
   if (mode != 2 && (!obs || !rew || !disc || !st || (mode == 0 && !act))) { h->err = "null device buffer"; return -1; }
   hipLaunchKernelGGL(flight_step_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->dm_dev, h->task_dev, h->states, act, obs, rew,
                      disc, st, h->batch, mode, nphys);
@@ -1566,6 +1613,7 @@ int ffe_physics_step(ffe_handle h, const float *ctrl, int nsteps, void *stream) 
 
 int ffe_force_next_episode(ffe_handle h, const int32_t *traj, const double *phase) {
   if (!h || !traj || !phase) return -1;
+  if (h->ball) { h->err = "walk_on_ball episodes have no per-episode randomness"; return -1; }
   try {
     int *dt = nullptr; double *dp = nullptr;
     HIP_OK(hipMalloc(reinterpret_cast<void **>(&dt), sizeof(int) * h->batch));
@@ -1581,22 +1629,26 @@ int ffe_force_next_episode(ffe_handle h, const int32_t *traj, const double *phas
 
 int ffe_get_state(ffe_handle h, double *qpos, double *qvel, void *stream) {
   if (!h || !qpos || !qvel) return -1;
+  FFE_BALL_DISPATCH(h, ffb::ball_get_state(h->ball, qpos, qvel, stream));
   hipLaunchKernelGGL(get_state_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->states, qpos, qvel, h->batch, h->dm.nq, h->dm.nv);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int ffe_set_state(ffe_handle h, const double *qpos, const double *qvel, void *stream) {
   if (!h || !qpos || !qvel) return -1;
+  FFE_BALL_DISPATCH(h, ffb::ball_set_state(h->ball, qpos, qvel, stream));
   hipLaunchKernelGGL(set_state_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->states, qpos, qvel, h->batch, h->dm.nq, h->dm.nv);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int ffe_get_task_state(ffe_handle h, int32_t *ints, double *reals, void *stream) {
   if (!h || !ints || !reals) return -1;
+  FFE_BALL_DISPATCH(h, ffb::ball_get_task_state(h->ball, ints, reals, stream));
   hipLaunchKernelGGL(get_task_state_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), h->states, ints, reals, h->batch);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int ffe_time_steps(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream, float *ms) {
   if (!h || !ms || iters <= 0) return -1;
+  FFE_BALL_DISPATCH(h, *ms = ffb::ball_time_steps(h->ball, act, obs, rew, disc, st, iters, stream));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipEventRecord(h->ev0, s) != hipSuccess) return -2;
   for (int i = 0; i < iters; i++) {

@@ -1,15 +1,15 @@
 """Environment factories with the reference's names and keyword meaning (`vnl_ray/fly_envs.py`), returning
 batched MI355X environments instead of single-instance `composer.Environment`s.
 
-Built so far: `flight_imitation` (`fly_envs.py:29-72`).  `walk_on_ball`, `walk_imitation`, `vision_guided_flight`
-and `template_task` are the next rows of SURVEY.md section 8 and raise `NotImplementedError` for now.
+Built so far: `flight_imitation` (`fly_envs.py:29-72`) and `walk_on_ball` (`fly_envs.py:125-157`).  `walk_imitation`,
+`vision_guided_flight` and `template_task` are later rows of SURVEY.md section 8 and raise `NotImplementedError`.
 """
 
 from __future__ import annotations
 
 import numpy as np
 
-from .batched_env import BatchedFlyEnv
+from .batched_env import BatchedBallEnv, BatchedFlyEnv
 from .tasks import synthetic, trajectories, wbpg
 
 
@@ -48,8 +48,14 @@ def flight_imitation(wpg_pattern_path: str | None = None, ref_path: str | None =
                          future_steps=5, time_limit=0.6, terminal_com_dist=terminal_com_dist, **env_kwargs)
 
 
-def walk_on_ball(*args, **kwargs):
-    raise NotImplementedError("walk_on_ball (contacts + ball arena) is the next SURVEY.md section 8 row; not built yet")
+def walk_on_ball(random_state=None, *, batch_size: int = 1, device: int = 0, **env_kwargs) -> BatchedBallEnv:
+    """Requires a tethered fruitfly to walk on a floating ball (`fly_envs.py:125-157`).
+
+    The arena (ball at (-0.05, 0, -0.419), radius 0.454, density 0.0025), `joint_filter=0.01`, `adhesion_filter=0.007`
+    and the claw friction are compiled into `assets/fly_ball.ffmb`; `time_limit` is 2.0 s.  Episodes carry no randomness
+    (`walk_on_ball.py:48-54`), so `random_state` is accepted for signature parity and ignored."""
+    del random_state
+    return BatchedBallEnv(batch_size=batch_size, device=device, time_limit=2.0, **env_kwargs)
 
 
 def walk_imitation(*args, **kwargs):

@@ -29,7 +29,8 @@ enum { FFE_STEP_FIRST = 0, FFE_STEP_MID = 1, FFE_STEP_LAST = 2 }; /* dm_env.Step
 
 /* physics switches (tests / BASELINE config 2 "constraints off"); 0 = everything on */
 enum {
-  FFE_NO_FLUID = 1, FFE_NO_LIMIT = 2, FFE_NO_DAMPER = 4, FFE_NO_SPRING = 8, FFE_NO_GRAVITY = 16, FFE_NO_ACTUATION = 32
+  FFE_NO_FLUID = 1, FFE_NO_LIMIT = 2, FFE_NO_DAMPER = 4, FFE_NO_SPRING = 8, FFE_NO_GRAVITY = 16, FFE_NO_ACTUATION = 32,
+  FFE_NO_CONTACT = 64, FFE_NO_NOSLIP = 128, FFE_NO_ADHESION = 256 /* walk_on_ball only */
 };
 
 /* Task inputs of fly_envs.flight_imitation (vnl_ray/fly_envs.py:29-72).  All host pointers, float64,
@@ -58,6 +59,17 @@ typedef struct {
   int32_t clip_actions;
 } ffe_flight_task;
 
+/* Task inputs of fly_envs.walk_on_ball (vnl_ray/fly_envs.py:125-157).  The arena (ball position / radius / density,
+ * tasks/arenas/ball.py:61-69), the actuator filters (joint_filter 0.01, adhesion_filter 0.007) and the claw friction
+ * (tasks/walk_on_ball.py:21,41-42) are compiled into the model blob (flybody_amd/assets/fly_ball.ffmb). */
+typedef struct {
+  double control_timestep;  /* tasks/constants.py:17 (2e-3 s; the model carries the 2e-4 s physics step) */
+  int32_t time_limit_steps; /* round(time_limit / control_timestep), fly_envs.py:144 (1000) */
+  int32_t pad_first_obs;    /* 0 = dm_control zero-padded sensor buffers at reset */
+  int32_t physics_flags;    /* FFE_NO_* */
+  int32_t canonical_actions, clip_actions; /* acme.wrappers.CanonicalSpecWrapper folded in, as in ffe_flight_task */
+} ffe_ball_task;
+
 typedef struct {
   int32_t batch, nq, nv, nu, action_dim, obs_dim, nsub;
   double physics_timestep, control_timestep;
@@ -70,6 +82,18 @@ typedef struct {
  * site agents/ray_distributed_dmpo.py:314.  `model_blob` is the compiled model (flybody_amd/assets). */
 int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight_task *task, int batch, int device,
                       uint64_t seed, uint64_t env_id_base, ffe_handle *out);
+/* fly_envs.walk_on_ball(...) -> composer.Environment (fly_envs.py:125-157): tethered fly walking on a floating ball
+ * (tasks/walk_on_ball.py:16-95; physics via MuJoCo mj_step with contacts, elliptic cones, noslip).  The returned handle
+ * works with ffe_spec / ffe_action_bounds / ffe_reset / ffe_step / ffe_physics_step / ffe_get_state / ffe_set_state /
+ * ffe_get_task_state / ffe_time_steps / ffe_destroy.  Observation row (289 floats): accelerometer 3 |
+ * actuator_activation 59 | appendages_pos 21 | ball_qvel 3 | force 18 | gyro 3 | joints_pos 85 | joints_vel 85 |
+ * touch 6 | velocimeter 3 | world_zaxis 3.  State layout: qpos[106] = ball quaternion, then the 102 hinges;
+ * qvel[105] = ball angular velocity (body frame), then the hinges. */
+int ffe_create_walk_on_ball(const void *model_blob, size_t blob_size, const ffe_ball_task *task, int batch, int device,
+                            ffe_handle *out);
+/* physics.data.act (actuator activations, [B][nu] float64 device buffers) of a walk_on_ball handle */
+int ffe_get_act(ffe_handle h, double *act_dev, void *stream);
+int ffe_set_act(ffe_handle h, const double *act_dev, void *stream);
 int ffe_destroy(ffe_handle h);
 
 /* observation_spec()/action_spec()/reward_spec()/discount_spec() (ray_distributed_dmpo.py:315) */

@@ -1,0 +1,203 @@
+"""GPU parity tests of the walk_on_ball HIP path (through the C ABI) against the float64 oracle on identical inputs.
+Run with `-m gpu` on an MI355X.  Float32 tolerances are stated per test; the oracle's own pinning is in
+tests/test_oracle_ball.py (the physics stays "parity unpinned" against MuJoCo itself)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+BALL_BLOB = os.path.join(ROOT, "flybody_amd", "assets", "fly_ball.ffmb")
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _oracle_states(n, amp, seed, settle=3):
+    """States (qpos, qvel, act) sampled along an oracle rollout under random actions: realistic contact sets."""
+    from oracle import oracle as O
+
+    m = O.OracleModel(BALL_BLOB)
+    env = O.OracleBallEnv(m)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    out = []
+    for k in range(n):
+        for _ in range(settle):
+            env.step(rs.uniform(-amp, amp, 59))
+        d = env.data
+        out.append((d.qpos.copy(), d.qvel.copy(), d.act.copy()))
+    return m, out
+
+
+def _oracle_advance(m, state, ctrl, nsteps, flags=0):
+    from oracle import oracle as O
+
+    d = O.OracleData(m)
+    m.set_flags(flags)
+    d.qpos[:], d.qvel[:], d.act[:] = state
+    d.ctrl[:] = ctrl
+    d.step1()
+    info = []
+    for _ in range(nsteps):
+        d.step2()
+        info.append((d.ncon, d.nefc, m.L.fo_solver_iter(d.ptr)))
+        d.step1()
+    m.set_flags(0)
+    return d.qpos.copy(), d.qvel.copy(), d.act.copy(), info
+
+
+def _gpu_advance(torch, states, ctrls, nsteps, flags=0):
+    from flybody_amd.batched_env import BatchedBallEnv
+
+    B = len(states)
+    env = BatchedBallEnv(batch_size=B, physics_flags=flags)
+    env.reset()
+    qpos = torch.tensor(np.stack([s[0] for s in states]), dtype=torch.float64, device="cuda")
+    qvel = torch.tensor(np.stack([s[1] for s in states]), dtype=torch.float64, device="cuda")
+    act = torch.tensor(np.stack([s[2] for s in states]), dtype=torch.float64, device="cuda")
+    env.set_state(qpos, qvel)
+    env.set_act(act)
+    env.physics_step(torch.tensor(np.stack(ctrls), dtype=torch.float32, device="cuda"), nsteps)
+    q, v = env.get_state()
+    a = env.get_act()
+    ints, _ = env.get_task_state()
+    torch.cuda.synchronize()
+    out = q.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy(), ints.cpu().numpy()
+    env.close()
+    return out
+
+
+def _report(tag, q, v, a, ref):
+    eq = max(np.abs(q[i] - r[0]).max() for i, r in enumerate(ref))
+    ev = max(np.abs(v[i] - r[1]).max() / max(1.0, np.abs(r[1]).max()) for i, r in enumerate(ref))
+    ea = max(np.abs(a[i] - r[2]).max() for i, r in enumerate(ref))
+    print(f"{tag}: qpos {eq:.3e} qvel(rel) {ev:.3e} act {ea:.3e}")
+    return eq, ev, ea
+
+
+@pytest.mark.parametrize("flags,name", [(64 | 2, "smooth"), (64, "limits"), (128 | 256, "contacts"), (128, "adhesion"), (0, "full")])
+def test_one_substep_teacher_forced(torch_mod, flags, name):
+    """One physics substep from oracle-sampled states: smooth dynamics only -> + joint limits -> + ball contacts
+    (elliptic Newton) -> + adhesion -> + noslip."""
+    m, states = _oracle_states(24, 0.6, seed=5)
+    rs = np.random.RandomState(11)
+    ctrls = [rs.uniform(-0.5, 0.5, 59).astype(np.float32) for _ in states]
+    ref = [_oracle_advance(m, s, c.astype(np.float64), 1, flags) for s, c in zip(states, ctrls)]
+    q, v, a, ints = _gpu_advance(torch_mod, states, ctrls, 1, flags)
+    eq, ev, ea = _report(name, q, v, a, ref)
+    if flags == 0:
+        print("contacts oracle", [r[3][0][0] for r in ref], "gpu", ints[:, 5].tolist(), "iters oracle", [r[3][0][2] for r in ref], "gpu", ints[:, 6].tolist())
+    assert ea < 1e-6
+    assert eq < 2e-6, name   # qpos moves by h * qvel: 2e-4 * O(10)
+    assert ev < 2e-3, name   # one substep of contact forces at float32
+
+
+def test_ten_substeps_open_loop(torch_mod):
+    m, states = _oracle_states(16, 0.4, seed=7)
+    rs = np.random.RandomState(3)
+    ctrls = [rs.uniform(-0.3, 0.3, 59).astype(np.float32) for _ in states]
+    ref = [_oracle_advance(m, s, c.astype(np.float64), 10) for s, c in zip(states, ctrls)]
+    q, v, a, _ = _gpu_advance(torch_mod, states, ctrls, 10)
+    eq, ev, ea = _report("10 substeps", q, v, a, ref)
+    assert eq < 2e-5 and ev < 1e-2 and ea < 1e-6
+
+
+def _obs_groups():
+    from oracle.oracle import OracleBallEnv
+
+    out, o = {}, 0
+    for name, n in OracleBallEnv.LAYOUT:
+        out[name] = (o, o + n)
+        o += n
+    return out
+
+
+def test_env_protocol_and_observation_parity(torch_mod):
+    """reset + 30 control steps with identical random raw actions: FIRST / MID protocol, reward, every observation group."""
+    from flybody_amd import fly_envs
+    from oracle import oracle as O
+
+    torch = torch_mod
+    B = 8
+    env = fly_envs.walk_on_ball(batch_size=B)
+    m = O.OracleModel(BALL_BLOB)
+    oenvs = [O.OracleBallEnv(m) for _ in range(B)]
+    ts = env.reset()
+    torch.cuda.synchronize()
+    groups = _obs_groups()
+    ref0 = [e.reset() for e in oenvs]
+    assert (ts.step_type.cpu().numpy() == 0).all() and ref0[0][0] == 0
+    obs = env.flat_observation.cpu().numpy()
+    worst = {}
+    for name, (lo, hi) in groups.items():
+        err = max(np.abs(obs[i, lo:hi] - ref0[i][3][lo:hi]).max() / max(1.0, np.abs(ref0[i][3][lo:hi]).max()) for i in range(B))
+        worst[name] = err
+    print("reset obs errors", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert max(worst.values()) < 1e-4
+    rs = np.random.RandomState(0)
+    werr, rerr = {k: 0.0 for k in groups}, 0.0
+    for t in range(30):
+        a = rs.uniform(-0.2, 0.2, (B, 59))
+        ts = env.step(torch.tensor(a, dtype=torch.float32, device="cuda"))
+        torch.cuda.synchronize()
+        obs = env.flat_observation.cpu().numpy()
+        rew = ts.reward.cpu().numpy()
+        for i, e in enumerate(oenvs):
+            st, r, dsc, o = e.step(a[i].astype(np.float32).astype(np.float64))
+            assert st == int(ts.step_type[i]) and dsc == float(ts.discount[i])
+            rerr = max(rerr, abs(r - rew[i]))
+            for name, (lo, hi) in groups.items():
+                werr[name] = max(werr[name], np.abs(obs[i, lo:hi] - o[lo:hi]).max() / max(1.0, np.abs(o[lo:hi]).max()))
+    print("30-step open-loop obs errors", {k: f"{v:.2e}" for k, v in werr.items()}, "reward", f"{rerr:.2e}")
+    assert rerr < 1e-3
+    assert werr["joints_pos"] < 1e-3 and werr["actuator_activation"] < 1e-5 and werr["appendages_pos"] < 1e-3
+    env.close()
+
+
+def test_time_limit_autoreset_and_determinism(torch_mod):
+    from flybody_amd.batched_env import BatchedBallEnv
+
+    torch = torch_mod
+    env = BatchedBallEnv(batch_size=4, time_limit=0.01)  # 5 control steps
+    env.reset()
+    a = torch.zeros(4, 59, dtype=torch.float32, device="cuda")
+    types = []
+    for _ in range(7):
+        ts = env.step(a)
+        types.append(ts.step_type.cpu().numpy().copy())
+    types = np.array(types)
+    assert (types[:4] == 1).all() and (types[4] == 2).all() and (types[5] == 0).all() and (types[6] == 1).all()
+    o1 = env.flat_observation.cpu().numpy().copy()
+    assert np.isfinite(o1).all() and np.abs(o1[0] - o1[3]).max() == 0.0  # identical envs stay bit-identical
+    env.close()
+
+
+def test_config3_batch_rollout_properties(torch_mod):
+    """BASELINE configs[2] shape (walk_on_ball, contacts, batch 4096): finite, bounded, contact counts within capacity."""
+    from flybody_amd import fly_envs
+
+    torch = torch_mod
+    B = 4096
+    env = fly_envs.walk_on_ball(batch_size=B)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(20):
+        a = (torch.rand(B, 59, device="cuda", generator=g) * 0.4 - 0.2).contiguous()
+        ts = env.step(a)
+    torch.cuda.synchronize()
+    obs = env.flat_observation
+    assert torch.isfinite(obs).all() and (ts.step_type == 1).all()
+    ints, _ = env.get_task_state()
+    assert int(ints[:, 5].max()) <= 12 and int(ints[:, 5].min()) >= 1
+    r = ts.reward
+    assert float(r.min()) >= 0.0 and float(r.max()) <= 1.0
+    env.close()
