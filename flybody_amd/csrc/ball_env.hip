@@ -53,8 +53,11 @@ struct alignas(16) BTile {
     struct { float A[2 * NC][2 * NC + 1], b[2 * NC], f[2 * NC]; } ns;  // noslip: unregularised tangential block
   };
   float frc[64];
-  int c_link[NC], c_blk[NC], c_excl[NC];
+  unsigned piv[NSTEP][16];  // pivot table of the block factorisation (copied from the model once per launch)
+  int c_link[NC], c_blk[NC], c_excl[NC], c_nch[NC], c_adh[NC];
   unsigned c_amask[NC];
+  unsigned char c_chain[NC][16];
+  float c_par[NC][8];  // K, B, invweight, friction, includemargin
   float c_pos[NC][3], c_frame[NC][9], c_dist[NC];
   float c_J[NC][3][NCH + 2], c_JB[NC][3][NCH + 2], c_Jb[NC][3][3], c_JBb[NC][3][3];
   float c_D[NC], c_mu[NC], c_aref[NC][3], c_f[NC][3], c_Hc[NC][9], c_jar[NC][3], c_jd[NC][3], c_w[NC][3];
@@ -62,38 +65,36 @@ struct alignas(16) BTile {
 };
 
 // ------------------------------------------------------------------------------------------------ per-lane context
+// Only what must survive between the stages lives here; model constants are re-read from the (L2-resident) tables
+// where they are used, through a laundered pointer so the compiler does not hoist them back into registers.
 struct Ctx {
   const BallModel *M;
   BTile *T;
   int lane, flags;
-  // link constants
-  int parent, depth, nchild, ch0, ch1, ch2, ndof;
-  V3 pos, ipos, inertia;
-  Q4 quat, iquat;
-  float mass, fl[8];
-  // dof slots (3 = haltere on lanes 0, 1)
-  int sdof[4], sblk[4], sli[4], slim[4];
-  V3 axis[3], jpos[3];
-  float stiff[4], sref[4], damp[4], lo[4], hi[4], invw[4], sK[4], sB[4];
-  float q[4], v[4];
-  // stage-1 results
+  unsigned lpack, lkids;  // parent + 1 | depth << 8 | ndof << 12 ;  children | nchild << 24
+  int sdof[3];
+  unsigned sbl[3];        // block | local index << 8 of each slot's dof
+  float q[3], v[3], fnb[3];
+  int xh;                 // this lane carries a haltere in slot 2 (closed-form single hinge, see ball_model.hpp)
   V3 xp, xip;
-  M3 xmat, ximat;
   Q4 xq;
-  S6 cdof[3], cdd[3], cvel, cfrc_ext_unused;
-  I10 cinert;
-  float fnb[4];
-  // ball (uniform across lanes)
+  S6 cvel, caccb;         // link velocity and bias acceleration (gravity + velocity products) about the thorax origin
+  float mass;
   Q4 bq;
   V3 bw, btau;
   int nc;
-  // entries of the joint-space inertia owned by this lane
-  unsigned emeta[ECAP];
-  unsigned eadr[ECAP];   // adr | fmask << 16
-  unsigned estep[ECAP];  // rowstep | colstep << 8 | diag adr << 16
+  unsigned e0[ECAP], e1[ECAP];  // e0: i | j << 8 | li_i << 16 | li_j << 20 | blk << 24 | valid << 31;  e1: adr | fmask << 10 | rowstep << 24 | colstep << 28
 };
 
 __device__ __forceinline__ bool slot_on(const Ctx &c, int s) { return c.sdof[s] >= 0; }
+__device__ __forceinline__ int l_parent(const Ctx &c) { return (int)(c.lpack & 0xffu) - 1; }
+__device__ __forceinline__ int l_depth(const Ctx &c) { return (int)((c.lpack >> 8) & 0xfu); }
+__device__ __forceinline__ int l_ndof(const Ctx &c) { return (int)((c.lpack >> 12) & 0x3u); }
+__device__ __forceinline__ const BallModel &model(const Ctx &c) {
+  const BallModel *m = c.M;
+  asm volatile("" : "+s"(m));
+  return *m;
+}
 
 // ------------------------------------------------------------------------------------------------ block factorisation
 // mj: mj_factorI restricted to M's 12 independent blocks, all blocks in lock step: at step s every block eliminates its
@@ -102,11 +103,10 @@ __device__ __forceinline__ bool slot_on(const Ctx &c, int s) { return c.sdof[s] 
 // `src` + diag(dadd) is factorised into `dst`; dinv receives 1 / D.
 __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, float *dst, float *dinv) {
   BTile &T = *c.T;
-  const BallModel &M = *c.M;
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
-    if (c.emeta[t] >> 31) {
-      const unsigned adr = c.eadr[t] & 0xffffu, i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu;
+    if (c.e0[t] >> 31) {
+      const unsigned adr = c.e1[t] & 0x3ffu, i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
       float vv = src[adr];
       if (use_add && i == j) vv += T.dadd[i];
       dst[adr] = vv;
@@ -117,12 +117,12 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
   for (int s = 0; s < NSTEP - 1; s++) {
 #pragma unroll
     for (int t = 0; t < ECAP; t++) {
-      if ((c.eadr[t] >> (16 + s)) & 1u) {
-        const unsigned meta = c.emeta[t], blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu, lij = (meta >> 20) & 0xfu;
-        const unsigned p = M.piv[s][blk], mk = p & 0xffffu, am = p >> 16;
+      if ((c.e1[t] >> (10 + s)) & 1u) {
+        const unsigned meta = c.e0[t], blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu, lij = (meta >> 20) & 0xfu;
+        const unsigned p = T.piv[s][blk], mk = p & 0xffffu, am = p >> 16;
         const unsigned oi = __popc(am & ~((2u << lii) - 1u)), oj = __popc(am & ~((2u << lij) - 1u));
         const float lkk = dst[mk], lki = dst[mk + oi], lkj = dst[mk + oj];
-        const unsigned adr = c.eadr[t] & 0xffffu;
+        const unsigned adr = c.e1[t] & 0x3ffu;
         dst[adr] -= lki * lkj / lkk;
       }
     }
@@ -130,18 +130,17 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
   }
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
-    if (c.emeta[t] >> 31) {
-      const unsigned adr = c.eadr[t] & 0xffffu, i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu, dadr = c.estep[t] >> 16;
-      const float dg = dst[dadr];
-      if (i == j) dinv[i] = 1.f / dg;
+    if (c.e0[t] >> 31) {
+      const unsigned i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
+      if (i == j) dinv[i] = 1.f / dst[c.e1[t] & 0x3ffu];
     }
   }
   DM_SYNC();
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
-    if (c.emeta[t] >> 31) {
-      const unsigned adr = c.eadr[t] & 0xffffu, i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu;
-      if (i != j) dst[adr] *= dinv[i];
+    if (c.e0[t] >> 31) {
+      const unsigned i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
+      if (i != j) dst[c.e1[t] & 0x3ffu] *= dinv[i];
     }
   }
   DM_SYNC();
@@ -154,9 +153,9 @@ __device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv
   for (int s = 0; s < NSTEP - 1; s++) {
 #pragma unroll
     for (int t = 0; t < ECAP; t++) {
-      const unsigned meta = c.emeta[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
-      if ((meta >> 31) && i != j && (c.estep[t] & 0xffu) == (unsigned)s) {
-        const float l = L[c.eadr[t] & 0xffffu];
+      const unsigned meta = c.e0[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
+      if ((meta >> 31) && i != j && ((c.e1[t] >> 24) & 0xfu) == (unsigned)s) {
+        const float l = L[c.e1[t] & 0x3ffu];
         const float4 xi = T.X4[i];
         float4 xj = T.X4[j];
         xj.x -= l * xi.x; xj.y -= l * xi.y; xj.z -= l * xi.z; xj.w -= l * xi.w;
@@ -176,9 +175,9 @@ __device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv
   for (int r = 0; r < NSTEP - 1; r++) {
 #pragma unroll
     for (int t = 0; t < ECAP; t++) {
-      const unsigned meta = c.emeta[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
-      if ((meta >> 31) && i != j && ((c.estep[t] >> 8) & 0xffu) == (unsigned)r) {
-        const float l = L[c.eadr[t] & 0xffffu];
+      const unsigned meta = c.e0[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
+      if ((meta >> 31) && i != j && (c.e1[t] >> 28) == (unsigned)r) {
+        const float l = L[c.e1[t] & 0x3ffu];
         const float4 xj = T.X4[j];
         float4 xi = T.X4[i];
         xi.x -= l * xj.x; xi.y -= l * xj.y; xi.z -= l * xj.z; xi.w -= l * xj.w;
@@ -191,15 +190,16 @@ __device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv
 
 // ------------------------------------------------------------------------------------------------ impedance
 // mj: getimpedance (margin folded into `x` by the caller: x = |pos - margin|)
-__device__ __forceinline__ float impedance(float d0, float d1, float width, float mid, float power, float x) {
-  d0 = fminf(fmaxf(d0, 1e-4f), 0.9999f); d1 = fminf(fmaxf(d1, 1e-4f), 0.9999f);
-  width = fmaxf(0.f, width); mid = fminf(fmaxf(mid, 1e-4f), 0.9999f); power = fmaxf(1.f, power);
+__device__ __forceinline__ float impedance(const float *si, float x) {
+  float d0 = fminf(fmaxf(si[0], 1e-4f), 0.9999f), d1 = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
+  const float width = fmaxf(0.f, si[2]), mid = fminf(fmaxf(si[3], 1e-4f), 0.9999f), power = fmaxf(1.f, si[4]);
   if (d0 == d1 || width <= 1e-15f) return 0.5f * (d0 + d1);
   x = x / width;
   if (x >= 1.f) return d1;
   if (x <= 0.f) return d0;
   float y;
   if (power == 1.f) y = x;
+  else if (power == 2.f) y = x <= mid ? x * x / mid : 1.f - (1.f - x) * (1.f - x) / (1.f - mid);
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
   else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
   return d0 + y * (d1 - d0);
@@ -208,26 +208,35 @@ __device__ __forceinline__ float impedance(float d0, float d1, float width, floa
 // ------------------------------------------------------------------------------------------------ stage 1
 __device__ __forceinline__ void stage1(Ctx &c) {
   BTile &T = *c.T;
-  const BallModel &M = *c.M;
-  const int lane = c.lane;
+  const BallModel &M = model(c);
+  const int lane = c.lane, depth = l_depth(c), parent = l_parent(c), ndof = l_ndof(c);
+  const int nchild = (int)(c.lkids >> 24), ch0 = (int)(c.lkids & 0xffu), ch1 = (int)((c.lkids >> 8) & 0xffu), ch2 = (int)((c.lkids >> 16) & 0xffu);
   const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
+  const V3 pos = {M.l_pos[0][lane], M.l_pos[1][lane], M.l_pos[2][lane]};
+  const Q4 quat = {M.l_quat[0][lane], M.l_quat[1][lane], M.l_quat[2][lane], M.l_quat[3][lane]};
+  V3 axis[3], jpos[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
+    jpos[s] = {M.s_jpos[0][s][lane], M.s_jpos[1][s][lane], M.s_jpos[2][s][lane]};
+  }
   // ---- mj: mj_kinematics, one tree level per sweep
   V3 axw[3], anc[3];
 #pragma unroll 1
   for (int d = 1; d <= M.maxdepth; d++) {
-    if (c.depth == d) {
+    if (depth == d) {
       Q4 pq = {1.f, 0.f, 0.f, 0.f};
       V3 pp = {0.f, 0.f, 0.f};
-      if (c.parent >= 0) { const float *p = T.lk[c.parent]; pp = {p[0], p[1], p[2]}; pq = {p[3], p[4], p[5], p[6]}; }
-      V3 xp = pp + qrot(pq, c.pos);
-      Q4 xq = qmul(pq, c.quat);
+      if (parent >= 0) { const float *p = T.lk[parent]; pp = {p[0], p[1], p[2]}; pq = {p[3], p[4], p[5], p[6]}; }
+      V3 xp = pp + qrot(pq, pos);
+      Q4 xq = qmul(pq, quat);
 #pragma unroll
       for (int s = 0; s < 3; s++) {
-        if (s < c.ndof) {
-          anc[s] = xp + qrot(xq, c.jpos[s]);
-          axw[s] = qrot(xq, c.axis[s]);
-          xq = qmul(xq, axis_angle(c.axis[s], c.q[s]));
-          xp = anc[s] - qrot(xq, c.jpos[s]);
+        if (s < ndof) {
+          anc[s] = xp + qrot(xq, jpos[s]);
+          axw[s] = qrot(xq, axis[s]);
+          xq = qmul(xq, axis_angle(axis[s], c.q[s]));
+          xp = anc[s] - qrot(xq, jpos[s]);
         }
       }
       xq = qnormalize(xq);
@@ -237,29 +246,30 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     }
     DM_SYNC();
   }
-  c.xmat = q2m(c.xq);
-  c.xip = c.xp + mv(c.xmat, c.ipos);
-  c.ximat = q2m(qmul(c.xq, c.iquat));
+  const M3 xmat = q2m(c.xq);
+  c.xip = c.xp + mv(xmat, V3{M.l_ipos[0][lane], M.l_ipos[1][lane], M.l_ipos[2][lane]});
+  const M3 ximat = q2m(qmul(c.xq, Q4{M.l_iquat[0][lane], M.l_iquat[1][lane], M.l_iquat[2][lane], M.l_iquat[3][lane]}));
+  c.mass = M.l_mass[lane];
   // ---- mj: mj_comPos with the fixed thorax origin as the reference point
-  c.cinert = inert_com(c.inertia, c.ximat, c.xip - c0, c.mass);
+  const I10 cinert = inert_com(V3{M.l_inertia[0][lane], M.l_inertia[1][lane], M.l_inertia[2][lane]}, ximat, c.xip - c0, c.mass);
+  S6 cdof[3];
 #pragma unroll
-  for (int s = 0; s < 3; s++) c.cdof[s] = s < c.ndof ? mk6(axw[s], cross(axw[s], c0 - anc[s])) : zero6();
+  for (int s = 0; s < 3; s++) cdof[s] = s < ndof ? mk6(axw[s], cross(axw[s], c0 - anc[s])) : zero6();
   // ---- mj: mj_comVel + the acceleration half of mj_rne, one level per sweep
-  S6 cacc = zero6();
 #pragma unroll 1
   for (int d = 1; d <= M.maxdepth; d++) {
-    if (c.depth == d) {
+    if (depth == d) {
       S6 pv = zero6(), pa = {0.f, 0.f, 0.f, 0.f, 0.f, (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz};
-      if (c.parent >= 0) { const float *p = T.lk[c.parent]; pv = ld6(p); pa = ld6(p + 6); }
+      if (parent >= 0) { const float *p = T.lk[parent]; pv = ld6(p); pa = ld6(p + 6); }
 #pragma unroll
       for (int s = 0; s < 3; s++) {
-        if (s < c.ndof) {
-          c.cdd[s] = cross_motion(pv, c.cdof[s]);
-          pv = pv + c.v[s] * c.cdof[s];
-          pa = pa + c.v[s] * c.cdd[s];
+        if (s < ndof) {
+          const S6 cdd = cross_motion(pv, cdof[s]);
+          pv = pv + c.v[s] * cdof[s];
+          pa = pa + c.v[s] * cdd;
         }
       }
-      c.cvel = pv; cacc = pa;
+      c.cvel = pv; c.caccb = pa;
       st6(T.lk[lane], pv); st6(T.lk[lane] + 6, pa);
     }
     DM_SYNC();
@@ -267,25 +277,28 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   // ---- body forces: rigid-body bias (mj_rne) minus inertia-box drag (mj_inertiaBoxFluidModel), about c0
   S6 ftot;
   {
-    const S6 t1 = mul_inert(c.cinert, cacc), t2 = mul_inert(c.cinert, c.cvel);
+    const S6 t1 = mul_inert(cinert, c.caccb), t2 = mul_inert(cinert, c.cvel);
     ftot = t1 + cross_force(c.cvel, t2);
     if (!(c.flags & BF_NO_FLUID)) {
+      float fl[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) fl[k] = M.l_fl[k][lane];
       const V3 r = c.xip - c0;
-      const V3 wl = mtv(c.ximat, ang(c.cvel)), vl = mtv(c.ximat, lin(c.cvel) + cross(ang(c.cvel), r));
-      const V3 Tl = {-c.fl[0] * wl.x - c.fl[5] * fabsf(wl.x) * wl.x, -c.fl[0] * wl.y - c.fl[6] * fabsf(wl.y) * wl.y, -c.fl[0] * wl.z - c.fl[7] * fabsf(wl.z) * wl.z};
-      const V3 Fl = {-c.fl[1] * vl.x - c.fl[2] * fabsf(vl.x) * vl.x, -c.fl[1] * vl.y - c.fl[3] * fabsf(vl.y) * vl.y, -c.fl[1] * vl.z - c.fl[4] * fabsf(vl.z) * vl.z};
-      const V3 Tw = mv(c.ximat, Tl), Fw = mv(c.ximat, Fl);
+      const V3 wl = mtv(ximat, ang(c.cvel)), vl = mtv(ximat, lin(c.cvel) + cross(ang(c.cvel), r));
+      const V3 Tl = {-fl[0] * wl.x - fl[5] * fabsf(wl.x) * wl.x, -fl[0] * wl.y - fl[6] * fabsf(wl.y) * wl.y, -fl[0] * wl.z - fl[7] * fabsf(wl.z) * wl.z};
+      const V3 Fl = {-fl[1] * vl.x - fl[2] * fabsf(vl.x) * vl.x, -fl[1] * vl.y - fl[3] * fabsf(vl.y) * vl.y, -fl[1] * vl.z - fl[4] * fabsf(vl.z) * vl.z};
+      const V3 Tw = mv(ximat, Tl), Fw = mv(ximat, Fl);
       ftot = ftot - mk6(Tw + cross(r, Fw), Fw);
     }
   }
   // ---- subtree sums (mj_crb's composite inertia and mj_rne's backward pass), leaves first
-  I10 crb = c.cinert;
+  I10 crb = cinert;
 #pragma unroll 1
   for (int d = M.maxdepth; d >= 1; d--) {
-    if (c.depth == d) {
-      if (c.nchild > 0) { const float *p = T.lk[c.ch0]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
-      if (c.nchild > 1) { const float *p = T.lk[c.ch1]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
-      if (c.nchild > 2) { const float *p = T.lk[c.ch2]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
+    if (depth == d) {
+      if (nchild > 0) { const float *p = T.lk[ch0]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
+      if (nchild > 1) { const float *p = T.lk[ch1]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
+      if (nchild > 2) { const float *p = T.lk[ch2]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
       st10(T.lk[lane], crb); st6(T.lk[lane] + 10, ftot);
     }
     DM_SYNC();
@@ -294,23 +307,22 @@ __device__ __forceinline__ void stage1(Ctx &c) {
 #pragma unroll
   for (int s = 0; s < 3; s++) {
     float f = 0.f;
-    if (s < c.ndof) {
-      if (!(c.flags & BF_NO_SPRING)) f -= c.stiff[s] * (c.q[s] - c.sref[s]);
-      if (!(c.flags & BF_NO_DAMPER)) f -= c.damp[s] * c.v[s];
-      f -= dot6(c.cdof[s], ftot);
+    if (s < ndof) {
+      if (!(c.flags & BF_NO_SPRING)) f -= M.s_stiff[s][lane] * (c.q[s] - M.s_sref[s][lane]);
+      if (!(c.flags & BF_NO_DAMPER)) f -= M.s_damp[s][lane] * c.v[s];
+      f -= dot6(cdof[s], ftot);
     }
     c.fnb[s] = f;
   }
-  c.fnb[3] = 0.f;
-  if (slot_on(c, 3)) {  // halteres: closed form (see ball_model.hpp)
+  if (c.xh) {  // halteres: closed form (see ball_model.hpp)
     float sn, cs;
-    sincosf(c.q[3], &sn, &cs);
+    sincosf(c.q[2], &sn, &cs);
     float f = 0.f;
-    if (!(c.flags & BF_NO_SPRING)) f -= c.stiff[3] * (c.q[3] - c.sref[3]);
-    if (!(c.flags & BF_NO_DAMPER)) f -= c.damp[3] * c.v[3];
+    if (!(c.flags & BF_NO_SPRING)) f -= M.s_stiff[2][lane] * (c.q[2] - M.s_sref[2][lane]);
+    if (!(c.flags & BF_NO_DAMPER)) f -= M.s_damp[2][lane] * c.v[2];
     if (!(c.flags & BF_NO_GRAVITY)) f += M.x_Gc[lane] * cs + M.x_Gs[lane] * sn;
-    if (!(c.flags & BF_NO_FLUID)) f -= M.x_cv[lane] * c.v[3] + M.x_cq[lane] * fabsf(c.v[3]) * c.v[3];
-    c.fnb[3] = f;
+    if (!(c.flags & BF_NO_FLUID)) f -= M.x_cv[lane] * c.v[2] + M.x_cq[lane] * fabsf(c.v[2]) * c.v[2];
+    c.fnb[2] = f;
   }
   // ball: isotropic sphere about its centre, only the box drag acts (mj_inertiaBoxFluidModel in the inertial frame)
   {
@@ -326,34 +338,35 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   // ---- mj: mj_crb joint-space inertia, one entry per (lane, slot t)
 #pragma unroll
   for (int s = 0; s < 3; s++) {
-    if (s < c.ndof) { st6(T.F[c.sdof[s]], mul_inert(crb, c.cdof[s])); st6(T.C[c.sdof[s]], c.cdof[s]); }
+    if (s < ndof) { st6(T.F[c.sdof[s]], mul_inert(crb, cdof[s])); st6(T.C[c.sdof[s]], cdof[s]); }
   }
-  if (slot_on(c, 3)) { st6(T.F[c.sdof[3]], S6{M.x_M[lane], 0.f, 0.f, 0.f, 0.f, 0.f}); st6(T.C[c.sdof[3]], S6{1.f, 0.f, 0.f, 0.f, 0.f, 0.f}); }
+  if (c.xh) { st6(T.F[c.sdof[2]], S6{M.x_M[lane], 0.f, 0.f, 0.f, 0.f, 0.f}); st6(T.C[c.sdof[2]], S6{1.f, 0.f, 0.f, 0.f, 0.f, 0.f}); }
   DM_SYNC();
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
-    if (c.emeta[t] >> 31) {
-      const unsigned i = c.emeta[t] & 0xffu, j = (c.emeta[t] >> 8) & 0xffu;
+    if (c.e0[t] >> 31) {
+      const unsigned i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
       float mij = dot6(ld6(T.C[j]), ld6(T.F[i]));
       if (i == j) mij += M.d_arm[i];
-      T.Mq[c.eadr[t] & 0xffffu] = mij;
+      T.Mq[c.e1[t] & 0x3ffu] = mij;
     }
   }
   DM_SYNC();
   factor(c, T.Mq, false, T.Lm, T.dinv_m);
   // ---- mj: mj_collision, ball (geom1, sphere) against this link's capsule: mjc_SphereCapsule
   bool hit = false;
-  float dist = 0.f;
+  float dist = 0.f, margin = 0.f, gap = 0.f;
   V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
   if (M.g_has[lane] && !(c.flags & BF_NO_CONTACT)) {
     const V3 bc = {M.b_center[0], M.b_center[1], M.b_center[2]};
-    const V3 gp = c.xp + mv(c.xmat, V3{M.g_pos[0][lane], M.g_pos[1][lane], M.g_pos[2][lane]});
-    const V3 ax = mv(c.xmat, V3{M.g_axis[0][lane], M.g_axis[1][lane], M.g_axis[2][lane]});
-    const float half = M.g_half[lane], x = fminf(fmaxf(dot(ax, bc - gp), -half), half);
+    const V3 gp = c.xp + mv(xmat, V3{M.g_pos[0][lane], M.g_pos[1][lane], M.g_pos[2][lane]});
+    const V3 ax = mv(xmat, V3{M.g_axis[0][lane], M.g_axis[1][lane], M.g_axis[2][lane]});
+    const float half = M.g_half[lane], rad = M.g_rad[lane], x = fminf(fmaxf(dot(ax, bc - gp), -half), half);
+    margin = M.g_margin[lane]; gap = M.g_gap[lane];
     const V3 dif = gp + x * ax - bc;
     const float cd = sqrtf(dot(dif, dif));
-    dist = cd - M.b_radius - M.g_rad[lane];
-    hit = cd <= M.g_margin[lane] + M.b_radius + M.g_rad[lane];
+    dist = cd - M.b_radius - rad;
+    hit = cd <= margin + M.b_radius + rad;
     if (cd >= 1e-15f) nrm = (1.f / cd) * dif;
     cpos = bc + (M.b_radius + 0.5f * dist) * nrm;
   }
@@ -362,11 +375,17 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   c.nc = min(__popcll(bal), NC);
   if (hit && idx < NC) {
     T.c_link[idx] = lane;
-    const int last = c.ndof == 1 ? c.sdof[0] : (c.ndof == 2 ? c.sdof[1] : c.sdof[2]);
+    const int last = ndof == 1 ? c.sdof[0] : (ndof == 2 ? c.sdof[1] : c.sdof[2]);
     T.c_blk[idx] = M.d_blk[last]; T.c_amask[idx] = M.d_amask[last];
-    T.c_excl[idx] = dist >= M.g_margin[lane] - M.g_gap[lane] ? 1 : 0;
+    T.c_excl[idx] = dist >= margin - gap ? 1 : 0;
     T.c_dist[idx] = dist;
     T.c_pos[idx][0] = cpos.x; T.c_pos[idx][1] = cpos.y; T.c_pos[idx][2] = cpos.z;
+    const int nch = M.l_nchain[lane];
+    T.c_nch[idx] = nch;
+    for (int p = 0; p < NCH; p++) T.c_chain[idx][p] = (unsigned char)(p < nch ? M.l_chain[p][lane] : 0);
+    T.c_par[idx][0] = M.g_K[lane]; T.c_par[idx][1] = M.g_B[lane]; T.c_par[idx][2] = M.g_invw[lane]; T.c_par[idx][3] = M.g_fric[lane];
+    T.c_par[idx][4] = margin - gap;
+    T.c_adh[idx] = M.l_adh[lane];
     // mj: mju_makeFrame
     V3 t1 = (nrm.y < 0.5f && nrm.y > -0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
     t1 = t1 - dot(nrm, t1) * nrm;
@@ -379,8 +398,10 @@ __device__ __forceinline__ void stage1(Ctx &c) {
 }
 
 // sum over the contacts whose chain contains fly dof (blk, li) of  sum_r J[c][r][p] * w[c][r]
-__device__ __forceinline__ float contact_gather(const Ctx &c, int blk, int li, const float (*w)[3]) {
+__device__ __forceinline__ float contact_gather(const Ctx &c, unsigned sbl, const float (*w)[3]) {
   const BTile &T = *c.T;
+  const int blk = (int)(sbl & 0xffu);
+  const unsigned li = sbl >> 8;
   float acc = 0.f;
   for (int k = 0; k < c.nc; k++) {
     if (T.c_blk[k] == blk && ((T.c_amask[k] >> li) & 1u)) {
@@ -391,7 +412,9 @@ __device__ __forceinline__ float contact_gather(const Ctx &c, int blk, int li, c
   return acc;
 }
 
-// mj: PrimalUpdateConstraint for one elliptic condim-3 contact (cost zones: DESIGN.md)
+// mj: PrimalUpdateConstraint for one elliptic condim-3 contact.  With U = mu (jar_n, jar_t1, jar_t2), N = U0, T = |U_t|:
+// zero force in the top zone N >= mu T, fully quadratic in the bottom zone mu N + T <= 0, and the cone-surface cost
+// Dm/2 (N - mu T)^2, Dm = D / (mu^2 (1 + mu^2)), in between.  Hc (optional) is the 3x3 Hessian of that cost in jar.
 __device__ __forceinline__ void cone_force(float D, float mu, float j0, float j1, float j2, float &f0, float &f1, float &f2, float *Hc) {
   const float N = j0 * mu, U1 = j1 * mu, U2 = j2 * mu, Tn = sqrtf(U1 * U1 + U2 * U2);
   if (Hc) for (int k = 0; k < 9; k++) Hc[k] = 0.f;
@@ -438,18 +461,29 @@ __device__ __forceinline__ bool qcqp2(float &x0, float &x1, float A00, float A01
   return active;
 }
 
+// contact-row residual jar = J a - aref for the contact owned by `lane` (a of the fly dofs staged in X4.x)
+__device__ __forceinline__ void contact_jar(const BTile &T, int k, V3 ab, float *jar) {
+  const int nch = T.c_nch[k];
+  jar[0] = -T.c_aref[k][0]; jar[1] = -T.c_aref[k][1]; jar[2] = -T.c_aref[k][2];
+  for (int p = 0; p < nch; p++) {
+    const float av = T.X4[T.c_chain[k][p]].x;
+    jar[0] += T.c_J[k][0][p] * av; jar[1] += T.c_J[k][1][p] * av; jar[2] += T.c_J[k][2][p] * av;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[k][r][0] * ab.x + T.c_Jb[k][r][1] * ab.y + T.c_Jb[k][r][2] * ab.z;
+}
+
 // ------------------------------------------------------------------------------------------------ stage 2
-// Returns the per-slot accelerations used for the termination guard through c (qacc in fa[]), integrates the state.
 __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, float &act_out, bool integrate, int &iters_out, float *qacc_norm2) {
   BTile &T = *c.T;
-  const BallModel &M = *c.M;
+  const BallModel &M = model(c);
   const int lane = c.lane;
   const int nc = c.nc;
   const float h = M.h;
   const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
   const V3 bc = {M.b_center[0], M.b_center[1], M.b_center[2]};
 #pragma unroll
-  for (int s = 0; s < 4; s++) if (slot_on(c, s)) { T.Q[c.sdof[s]] = c.q[s]; T.V[c.sdof[s]] = c.v[s]; }
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { T.Q[c.sdof[s]] = c.q[s]; T.V[c.sdof[s]] = c.v[s]; }
   DM_SYNC();
   // ---- mj: mj_fwdActuation: first-order activation filter, affine position servo on the activation
   float act_dot = 0.f;
@@ -460,7 +494,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       if (M.a_climited[lane]) ctrl = fminf(fmaxf(ctrl, M.a_clo[lane]), M.a_chi[lane]);
       act_dot = (ctrl - act_reg) / M.a_tau[lane];
       float length = 0.f, vel = 0.f;
-      for (int w = 0; w < M.a_nwrap[lane]; w++) { const int f = M.a_wdof[w][lane]; length += M.a_wcoef[w][lane] * T.Q[f]; vel += M.a_wcoef[w][lane] * T.V[f]; }
+      const int nw = M.a_nwrap[lane];
+      for (int w = 0; w < nw; w++) { const int f = M.a_wdof[w][lane]; const float cf = M.a_wcoef[w][lane]; length += cf * T.Q[f]; vel += cf * T.V[f]; }
       force = M.a_gain[lane] * act_reg + M.a_b0[lane] + M.a_b1[lane] * length + M.a_b2[lane] * vel;
       if (M.a_flimited[lane]) force = fminf(fmaxf(force, M.a_flo[lane]), M.a_fhi[lane]);
       if (M.a_trn[lane] == 2 && (c.flags & BF_NO_ADHESION)) force = 0.f;
@@ -469,14 +504,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   act_out = act_reg + h * act_dot;
   // ---- contact rows: Jacobians over the chain dofs (jac2 - jac1, geom1 = ball), impedance, reference acceleration
-  Q4 bq = c.bq;
-  const M3 Rb = q2m(bq);
+  const M3 Rb = q2m(c.bq);
   DM_SYNC();
   for (int item = lane; item < nc * NCH; item += 64) {
-    const int k = item / NCH, p = item - k * NCH, l = T.c_link[k], f = M.l_chain[p][l];
+    const int k = item / NCH, p = item - k * NCH;
     float j0 = 0.f, j1 = 0.f, j2 = 0.f;
-    if (f >= 0) {
-      const S6 cd = ld6(T.C[f]);
+    if (p < T.c_nch[k]) {
+      const S6 cd = ld6(T.C[T.c_chain[k][p]]);
       const V3 r = V3{T.c_pos[k][0], T.c_pos[k][1], T.c_pos[k][2]} - c0;
       const V3 u = lin(cd) + cross(ang(cd), r);
       const float *fr = T.c_frame[k];
@@ -499,37 +533,37 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   DM_SYNC();
   // per-contact parameters (lane = contact) and the adhesion pull (mj: mj_transmission mjTRN_BODY: -force along the normal row)
   if (lane < nc) {
-    const int l = T.c_link[lane], nch = M.l_nchain[l];
+    const int nch = T.c_nch[lane];
     float vel[3] = {0.f, 0.f, 0.f};
     for (int p = 0; p < nch; p++) {
-      const float vv = T.V[M.l_chain[p][l]];
+      const float vv = T.V[T.c_chain[lane][p]];
       vel[0] += T.c_J[lane][0][p] * vv; vel[1] += T.c_J[lane][1][p] * vv; vel[2] += T.c_J[lane][2][p] * vv;
     }
 #pragma unroll
     for (int r = 0; r < 3; r++) vel[r] += T.c_Jb[lane][r][0] * c.bw.x + T.c_Jb[lane][r][1] * c.bw.y + T.c_Jb[lane][r][2] * c.bw.z;
-    const float incl = M.g_margin[l] - M.g_gap[l], dist = T.c_dist[lane];
-    const float imp = impedance(M.g_solimp[0][l], M.g_solimp[1][l], M.g_solimp[2][l], M.g_solimp[3][l], M.g_solimp[4][l], fabsf(dist - incl));
-    const float R0 = fmaxf(1e-15f, (1.f - imp) * M.g_invw[l] / imp);
+    const float K = T.c_par[lane][0], B = T.c_par[lane][1], invw = T.c_par[lane][2], incl = T.c_par[lane][4], dist = T.c_dist[lane];
+    const float imp = impedance(M.c_solimp, fabsf(dist - incl));
+    const float R0 = fmaxf(1e-15f, (1.f - imp) * invw / imp);
     T.c_D[lane] = T.c_excl[lane] ? 0.f : 1.f / R0;
-    T.c_mu[lane] = M.g_fric[l];
-    T.c_aref[lane][0] = -M.g_B[l] * vel[0] - M.g_K[l] * imp * (dist - incl);
-    T.c_aref[lane][1] = -M.g_B[l] * vel[1];
-    T.c_aref[lane][2] = -M.g_B[l] * vel[2];
-    const int adh = M.l_adh[l];
+    T.c_mu[lane] = T.c_par[lane][3];
+    T.c_aref[lane][0] = -B * vel[0] - K * imp * (dist - incl);
+    T.c_aref[lane][1] = -B * vel[1];
+    T.c_aref[lane][2] = -B * vel[2];
+    const int adh = T.c_adh[lane];
     T.c_w[lane][0] = adh >= 0 ? -T.frc[adh] : 0.f; T.c_w[lane][1] = 0.f; T.c_w[lane][2] = 0.f;
   }
   DM_SYNC();
   // ---- smooth forces and accelerations (mj: mj_fwdAcceleration)
-  float qs[4], am[4];
+  float qs[3], am[3];
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  for (int s = 0; s < 3; s++) {
     qs[s] = 0.f;
     if (slot_on(c, s)) {
       float f = c.fnb[s];
       const int a0 = M.s_act[0][s][lane], a1 = M.s_act[1][s][lane];
       if (a0 >= 0) f += M.s_actcoef[0][s][lane] * T.frc[a0];
       if (a1 >= 0) f += M.s_actcoef[1][s][lane] * T.frc[a1];
-      if (nc) f += contact_gather(c, c.sblk[s], c.sli[s], T.c_w);
+      if (nc) f += contact_gather(c, c.sbl[s], T.c_w);
       qs[s] = f;
       T.X4[c.sdof[s]] = make_float4(f, 0.f, 0.f, 0.f);
     }
@@ -541,55 +575,50 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   DM_SYNC();
   solve4(c, T.Lm, T.dinv_m);
 #pragma unroll
-  for (int s = 0; s < 4; s++) am[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
+  for (int s = 0; s < 3; s++) am[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
   const float Ib = M.b_I;
   const V3 amb = (1.f / Ib) * qsb;
   // ---- joint-limit rows (mj: mj_instantiateLimit, margin 0): sign, D, aref per slot
-  float lsgn[4], lD[4], laref[4];
+  float lsgn[3], lD[3], laref[3];
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  for (int s = 0; s < 3; s++) {
     lsgn[s] = 0.f; lD[s] = 0.f; laref[s] = 0.f;
-    if (slot_on(c, s) && c.slim[s] && !(c.flags & BF_NO_LIMIT)) {
-      const float dlo = c.q[s] - c.lo[s], dhi = c.hi[s] - c.q[s];
+    if (slot_on(c, s) && M.s_limited[s][lane] && !(c.flags & BF_NO_LIMIT)) {
+      const float dlo = c.q[s] - M.s_lo[s][lane], dhi = M.s_hi[s][lane] - c.q[s];
       float dist = 0.f;
       if (dlo < 0.f) { lsgn[s] = 1.f; dist = dlo; }
       else if (dhi < 0.f) { lsgn[s] = -1.f; dist = dhi; }
       if (lsgn[s] != 0.f) {
-        const float imp = impedance(M.s_solimp[0][s][lane], M.s_solimp[1][s][lane], M.s_solimp[2][s][lane], M.s_solimp[3][s][lane], M.s_solimp[4][s][lane], fabsf(dist));
-        lD[s] = 1.f / fmaxf(1e-15f, (1.f - imp) * c.invw[s] / imp);
-        laref[s] = -c.sB[s] * (lsgn[s] * c.v[s]) - c.sK[s] * imp * dist;
+        const float imp = impedance(M.j_solimp, fabsf(dist));
+        lD[s] = 1.f / fmaxf(1e-15f, (1.f - imp) * M.s_invw[s][lane] / imp);
+        laref[s] = -M.s_B[s][lane] * (lsgn[s] * c.v[s]) - M.s_K[s][lane] * imp * dist;
       }
     }
   }
   // ---- mj: mj_fwdConstraint - Newton on 1/2 (a - a_s)' M (a - a_s) + s(J a - aref), started at a_s
-  float a[4], Ma[4];
+  float a[3], Ma[3];
 #pragma unroll
-  for (int s = 0; s < 4; s++) { a[s] = am[s]; Ma[s] = qs[s]; }
+  for (int s = 0; s < 3; s++) { a[s] = am[s]; Ma[s] = qs[s]; }
   V3 ab = amb;
   int any_lim = 0;
 #pragma unroll
-  for (int s = 0; s < 4; s++) any_lim |= (lsgn[s] != 0.f);
+  for (int s = 0; s < 3; s++) any_lim |= (lsgn[s] != 0.f);
   int nact = 0;
   for (int k = 0; k < nc; k++) nact += T.c_excl[k] ? 0 : 1;
   const bool constrained = __any(any_lim) || nact > 0;
   int iters = 0;
-  float lf[4] = {0.f, 0.f, 0.f, 0.f};
+  float lf[3] = {0.f, 0.f, 0.f};
   if (constrained) {
 #pragma unroll 1
     for (int it = 0; it < kMaxNewton; it++) {
       // contact residuals, forces, local Hessians (lane = contact)
 #pragma unroll
-      for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
       DM_SYNC();
       if (lane < nc) {
-        const int l = T.c_link[lane], nch = M.l_nchain[l];
-        float jar[3] = {-T.c_aref[lane][0], -T.c_aref[lane][1], -T.c_aref[lane][2]};
-        for (int p = 0; p < nch; p++) {
-          const float av = T.X4[M.l_chain[p][l]].x;
-          jar[0] += T.c_J[lane][0][p] * av; jar[1] += T.c_J[lane][1][p] * av; jar[2] += T.c_J[lane][2][p] * av;
-        }
-#pragma unroll
-        for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[lane][r][0] * ab.x + T.c_Jb[lane][r][1] * ab.y + T.c_Jb[lane][r][2] * ab.z;
+        const int nch = T.c_nch[lane];
+        float jar[3];
+        contact_jar(T, lane, ab, jar);
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, Hc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (!T.c_excl[lane]) cone_force(T.c_D[lane], T.c_mu[lane], jar[0], jar[1], jar[2], f0, f1, f2, Hc);
         T.c_jar[lane][0] = jar[0]; T.c_jar[lane][1] = jar[1]; T.c_jar[lane][2] = jar[2];
@@ -612,10 +641,10 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       }
       DM_SYNC();
       // gradient (fly slots + ball), Hessian diagonal additions, coupling columns
-      float g[4], hadd[4], hfb[4][3];
+      float g[3], hadd[3], hfb[3][3];
       float gn2 = 0.f, fn2 = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < 3; s++) {
         g[s] = 0.f; hadd[s] = 0.f; lf[s] = 0.f; hfb[s][0] = hfb[s][1] = hfb[s][2] = 0.f;
         if (slot_on(c, s)) {
           float gg = Ma[s] - qs[s];
@@ -624,10 +653,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
             if (r < 0.f) { lf[s] = -lD[s] * r; gg -= lsgn[s] * lf[s]; hadd[s] = lD[s]; }
           }
           if (nc) {
-            gg -= contact_gather(c, c.sblk[s], c.sli[s], T.c_f);
+            gg -= contact_gather(c, c.sbl[s], T.c_f);
+            const int blk = (int)(c.sbl[s] & 0xffu);
+            const unsigned li = c.sbl[s] >> 8;
             for (int k = 0; k < nc; k++) {
-              if (T.c_blk[k] == c.sblk[s] && ((T.c_amask[k] >> c.sli[s]) & 1u)) {
-                const int p = __popc(T.c_amask[k] & ((1u << c.sli[s]) - 1u));
+              if (T.c_blk[k] == blk && ((T.c_amask[k] >> li) & 1u)) {
+                const int p = __popc(T.c_amask[k] & ((1u << li) - 1u));
                 const float x0 = T.c_J[k][0][p], x1 = T.c_J[k][1][p], x2 = T.c_J[k][2][p];
 #pragma unroll
                 for (int m = 0; m < 3; m++) hfb[s][m] += x0 * T.c_JBb[k][0][m] + x1 * T.c_JBb[k][1][m] + x2 * T.c_JBb[k][2][m];
@@ -663,9 +694,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       DM_SYNC();
 #pragma unroll
       for (int t = 0; t < ECAP; t++) {
-        if (c.emeta[t] >> 31) {
-          const unsigned meta = c.emeta[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu, blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu,
-                         lij = (meta >> 20) & 0xfu, adr = c.eadr[t] & 0xffffu;
+        if (c.e0[t] >> 31) {
+          const unsigned meta = c.e0[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu, blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu,
+                         lij = (meta >> 20) & 0xfu, adr = c.e1[t] & 0x3ffu;
           float hv = T.Mq[adr];
           if (i == j) hv += T.dadd[i];
           for (int k = 0; k < nc; k++) {
@@ -682,13 +713,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       factor(c, T.Lh, false, T.Lh, T.dinv_h);
       // [ -g_f | H_fb ] through H_ff^-1, then the 3x3 Schur complement on the ball
 #pragma unroll
-      for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = make_float4(-g[s], hfb[s][0], hfb[s][1], hfb[s][2]);
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = make_float4(-g[s], hfb[s][0], hfb[s][1], hfb[s][2]);
       DM_SYNC();
       solve4(c, T.Lh, T.dinv_h);
-      float4 xs[4];
+      float4 xs[3];
       float sc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // S reductions: xx xy xz yy yz zz, rhs x y z
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < 3; s++) {
         xs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot_on(c, s)) {
           xs[s] = T.X4[c.sdof[s]];
@@ -709,18 +740,18 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         const float y0 = r0 / l00, y1 = (r1 - l10 * y0) / l11, y2 = (r2 - l20 * y0 - l21 * y1) / l22;
         db.z = y2 / l22; db.y = (y1 - l21 * db.z) / l11; db.x = (y0 - l10 * db.y - l20 * db.z) / l00;
       } else db = (-1.f / Ib) * gb;
-      float dd[4];
+      float dd[3];
 #pragma unroll
-      for (int s = 0; s < 4; s++) dd[s] = xs[s].x - xs[s].y * db.x - xs[s].z * db.y - xs[s].w * db.z;
+      for (int s = 0; s < 3; s++) dd[s] = xs[s].x - xs[s].y * db.x - xs[s].z * db.y - xs[s].w * db.z;
       // jd = J d per row; Md = -g - (H - M) d
 #pragma unroll
-      for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = dd[s];
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = dd[s];
       DM_SYNC();
       if (lane < nc) {
-        const int l = T.c_link[lane], nch = M.l_nchain[l];
+        const int nch = T.c_nch[lane];
         float jd[3] = {0.f, 0.f, 0.f};
         for (int p = 0; p < nch; p++) {
-          const float dv = T.X4[M.l_chain[p][l]].x;
+          const float dv = T.X4[T.c_chain[lane][p]].x;
           jd[0] += T.c_J[lane][0][p] * dv; jd[1] += T.c_J[lane][1][p] * dv; jd[2] += T.c_J[lane][2][p] * dv;
         }
 #pragma unroll
@@ -732,13 +763,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         T.c_w[lane][2] = Hc[6] * jd[0] + Hc[7] * jd[1] + Hc[8] * jd[2];
       }
       DM_SYNC();
-      float Md[4], c0s = 0.f, c1s = 0.f;
+      float Md[3], c0s = 0.f, c1s = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < 3; s++) {
         Md[s] = 0.f;
         if (slot_on(c, s)) {
           float md = -g[s] - hadd[s] * dd[s];
-          if (nc) md -= contact_gather(c, c.sblk[s], c.sli[s], T.c_w);
+          if (nc) md -= contact_gather(c, c.sbl[s], T.c_w);
           Md[s] = md;
           c0s += (Ma[s] - qs[s]) * dd[s]; c1s += md * dd[s];
         }
@@ -749,7 +780,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       auto dphi = [&](float al) {
         float acc = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < 3; s++) {
           if (lsgn[s] != 0.f) {
             const float jdv = lsgn[s] * dd[s], r = lsgn[s] * a[s] - laref[s] + al * jdv;
             if (r < 0.f) acc += lD[s] * r * jdv;
@@ -774,6 +805,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         else {
 #pragma unroll 1
           for (int ls = 0; ls < kLsIter; ls++) {
+            if (fabsf(dhi) <= 1e-6f * fabsf(d0)) { lo = hi; dlo = dhi; break; }
             // regula falsi step safeguarded by bisection
             float mid = lo - dlo * (hi - lo) / (dhi - dlo);
             if (!(mid > lo + 0.05f * (hi - lo)) || !(mid < hi - 0.05f * (hi - lo))) mid = 0.5f * (lo + hi);
@@ -781,33 +813,27 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
             if (dm_ < 0.f) { lo = mid; dlo = dm_; } else { hi = mid; dhi = dm_; }
             if (fabsf(dm_) <= 1e-6f * fabsf(d0) || hi - lo <= 1e-6f * hi) break;
           }
-          alpha = lo - dlo * (hi - lo) / (dhi - dlo);
+          alpha = (dhi - dlo) != 0.f ? lo - dlo * (hi - lo) / (dhi - dlo) : hi;
           if (!(alpha >= lo) || !(alpha <= hi)) alpha = 0.5f * (lo + hi);
         }
       }
 #pragma unroll
-      for (int s = 0; s < 4; s++) { a[s] += alpha * dd[s]; Ma[s] += alpha * Md[s]; }
+      for (int s = 0; s < 3; s++) { a[s] += alpha * dd[s]; Ma[s] += alpha * Md[s]; }
       ab = ab + alpha * db;
     }
     // final forces at the solution
 #pragma unroll
-    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
     DM_SYNC();
     if (lane < nc) {
-      const int l = T.c_link[lane], nch = M.l_nchain[l];
-      float jar[3] = {-T.c_aref[lane][0], -T.c_aref[lane][1], -T.c_aref[lane][2]};
-      for (int p = 0; p < nch; p++) {
-        const float av = T.X4[M.l_chain[p][l]].x;
-        jar[0] += T.c_J[lane][0][p] * av; jar[1] += T.c_J[lane][1][p] * av; jar[2] += T.c_J[lane][2][p] * av;
-      }
-#pragma unroll
-      for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[lane][r][0] * ab.x + T.c_Jb[lane][r][1] * ab.y + T.c_Jb[lane][r][2] * ab.z;
+      float jar[3];
+      contact_jar(T, lane, ab, jar);
       float f0 = 0.f, f1 = 0.f, f2 = 0.f;
       if (!T.c_excl[lane]) cone_force(T.c_D[lane], T.c_mu[lane], jar[0], jar[1], jar[2], f0, f1, f2, nullptr);
       T.c_f[lane][0] = f0; T.c_f[lane][1] = f1; T.c_f[lane][2] = f2;
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 3; s++) {
       lf[s] = 0.f;
       if (lsgn[s] != 0.f) { const float r = lsgn[s] * a[s] - laref[s]; if (r < 0.f) lf[s] = -lD[s] * r; }
     }
@@ -827,9 +853,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     for (int k = lane; k < nc; k += 64) { T.c_w[k][0] = T.c_f[k][0]; T.c_w[k][1] = 0.f; T.c_w[k][2] = 0.f; }
     DM_SYNC();
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 3; s++) {
       if (slot_on(c, s)) {
-        float f = lsgn[s] * lf[s] + contact_gather(c, c.sblk[s], c.sli[s], T.c_w);
+        float f = lsgn[s] * lf[s] + contact_gather(c, c.sbl[s], T.c_w);
         T.X4[c.sdof[s]] = make_float4(f, 0.f, 0.f, 0.f);
       }
     }
@@ -840,27 +866,21 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     w0b = (1.f / Ib) * w0b;
     DM_SYNC();
     solve4(c, T.Lm, T.dinv_m);
-    float w0[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) w0[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
     // b' = J_t (a_smooth + w0) - aref_t  (lane = tangential row)
 #pragma unroll
-    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = am[s] + w0[s];
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x += am[s];
     DM_SYNC();
     float brow = 0.f;
     if (lane < nr) {
-      const int k = lane >> 1, r = 1 + (lane & 1), l = T.c_link[k], nch = M.l_nchain[l];
+      const int k = lane >> 1, r = 1 + (lane & 1), nch = T.c_nch[k];
       float sacc = -T.c_aref[k][r];
-      for (int p = 0; p < nch; p++) sacc += T.c_J[k][r][p] * T.X4[M.l_chain[p][l]].x;
+      for (int p = 0; p < nch; p++) sacc += T.c_J[k][r][p] * T.X4[T.c_chain[k][p]].x;
       const V3 ub = amb + w0b;
       sacc += T.c_Jb[k][r][0] * ub.x + T.c_Jb[k][r][1] * ub.y + T.c_Jb[k][r][2] * ub.z;
       brow = sacc;
     }
     DM_SYNC();
-    // A_tt, four columns per solve
-    float arow[2 * NC];
-#pragma unroll
-    for (int k = 0; k < 2 * NC; k++) arow[k] = 0.f;
+    // A_tt, four columns per solve, written straight into the (idle) link-exchange buffer
 #pragma unroll 1
     for (int base = 0; base < nr; base += 4) {
       for (int f = lane; f < ND; f += 64) T.X4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -868,18 +888,18 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       for (int item = lane; item < 4 * NCH; item += 64) {
         const int col = item / NCH, p = item - col * NCH, row = base + col;
         if (row < nr) {
-          const int k = row >> 1, r = 1 + (row & 1), l = T.c_link[k], f = M.l_chain[p][l];
-          if (f >= 0) (&T.X4[f].x)[col] = T.c_J[k][r][p];
+          const int k = row >> 1, r = 1 + (row & 1);
+          if (p < T.c_nch[k]) (&T.X4[T.c_chain[k][p]].x)[col] = T.c_J[k][r][p];
         }
       }
       DM_SYNC();
       solve4(c, T.Lm, T.dinv_m);
       if (lane < nr) {
-        const int k = lane >> 1, r = 1 + (lane & 1), l = T.c_link[k], nch = M.l_nchain[l];
+        const int k = lane >> 1, r = 1 + (lane & 1), nch = T.c_nch[k];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int p = 0; p < nch; p++) {
           const float jv = T.c_J[k][r][p];
-          const float4 y = T.X4[M.l_chain[p][l]];
+          const float4 y = T.X4[T.c_chain[k][p]];
           acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
         }
 #pragma unroll
@@ -888,18 +908,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           if (row < nr) {
             const int k2 = row >> 1, r2 = 1 + (row & 1);
             const float ball = (T.c_Jb[k][r][0] * T.c_Jb[k2][r2][0] + T.c_Jb[k][r][1] * T.c_Jb[k2][r2][1] + T.c_Jb[k][r][2] * T.c_Jb[k2][r2][2]) / Ib;
-            const float val = (col == 0 ? acc.x : (col == 1 ? acc.y : (col == 2 ? acc.z : acc.w))) + ball;
-#pragma unroll
-            for (int q2 = 0; q2 < 2 * NC; q2++) if (q2 == row) arow[q2] = val;
+            T.ns.A[lane][row] = (col == 0 ? acc.x : (col == 1 ? acc.y : (col == 2 ? acc.z : acc.w))) + ball;
           }
         }
       }
       DM_SYNC();
     }
-    // stage A, b, f in LDS (aliases the link-exchange buffer, idle here), then sweep
     if (lane < nr) {
-#pragma unroll
-      for (int q2 = 0; q2 < 2 * NC; q2++) T.ns.A[lane][q2] = arow[q2];
       T.ns.b[lane] = brow;
       T.ns.f[lane] = T.c_f[lane >> 1][1 + (lane & 1)];
     }
@@ -926,8 +941,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           }
         }
         const float d0 = v0 - o0, d1 = v1 - o1;
-        float change = d0 * res0 + d1 * res1 + 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1));
-        if (change > 1e-10f) { v0 = o0; v1 = o1; change = 0.f; }
+        // mj: costChange reverts an update whose cost change is > 1e-10 (a failed QCQP).  In float32 the two terms below cancel
+        // to ~1e-7 of their size, so the revert threshold is taken relative to them; a genuine failure is far above it.
+        const float lin_ = d0 * res0 + d1 * res1, quad_ = 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1));
+        float change = lin_ + quad_;
+        if (change > 1e-10f + 1e-4f * (fabsf(lin_) + fabsf(quad_))) { v0 = o0; v1 = o1; change = 0.f; }
+        change = fminf(change, 0.f);
         improvement -= change;
         DM_SYNC();
         if (lane == 0) { T.ns.f[r0] = v0; T.ns.f[r1] = v1; }
@@ -939,13 +958,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     DM_SYNC();
   }
   // ---- constraint forces in joint space, final acceleration
-  float qc[4];
+  float qc[3];
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  for (int s = 0; s < 3; s++) {
     qc[s] = 0.f;
     if (slot_on(c, s)) {
       qc[s] = lsgn[s] * lf[s];
-      if (nc) qc[s] += contact_gather(c, c.sblk[s], c.sli[s], T.c_f);
+      if (nc) qc[s] += contact_gather(c, c.sbl[s], T.c_f);
     }
   }
   V3 qcb = {0.f, 0.f, 0.f};
@@ -955,44 +974,28 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     qcb.y += T.c_Jb[k][0][1] * f0 + T.c_Jb[k][1][1] * f1 + T.c_Jb[k][2][1] * f2;
     qcb.z += T.c_Jb[k][0][2] * f0 + T.c_Jb[k][1][2] * f1 + T.c_Jb[k][2][2] * f2;
   }
-  // Euler with implicit joint damping (mj: mj_Euler): (M + h B) qacc_e = qfrc_smooth + qfrc_constraint; with noslip the
-  // unconstrained-metric acceleration qacc = a_s + M^-1 J' f rides along as a second right-hand side
+  if (did_noslip) {  // qacc = a_s + M^-1 J' f with the swept forces
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    if (slot_on(c, s)) {
-      T.dadd[c.sdof[s]] = (c.flags & BF_NO_DAMPER) ? 0.f : h * c.damp[s];
-      T.X4[c.sdof[s]] = make_float4(qs[s] + qc[s], 0.f, 0.f, 0.f);
-    }
-  }
-  DM_SYNC();
-  float qacc[4];
-  if (did_noslip) {
-    float4 keep[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) keep[s] = slot_on(c, s) ? T.X4[c.sdof[s]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = qc[s];
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = make_float4(qc[s], 0.f, 0.f, 0.f);
     DM_SYNC();
     solve4(c, T.Lm, T.dinv_m);
 #pragma unroll
-    for (int s = 0; s < 4; s++) { a[s] = slot_on(c, s) ? am[s] + T.X4[c.sdof[s]].x : 0.f; }
+    for (int s = 0; s < 3; s++) a[s] = slot_on(c, s) ? am[s] + T.X4[c.sdof[s]].x : 0.f;
     ab = amb + (1.f / Ib) * qcb;
     DM_SYNC();
-#pragma unroll
-    for (int s = 0; s < 4; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = keep[s];
-    DM_SYNC();
   }
-#pragma unroll
-  for (int s = 0; s < 4; s++) qacc[s] = a[s];
   {
     float n2 = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; s++) if (slot_on(c, s)) n2 += qacc[s] * qacc[s];
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) n2 += a[s] * a[s];
     *qacc_norm2 = wave_sum(n2) + dot(ab, ab);
   }
   // ---- sensors (mj: mj_rnePostConstraint + mj_sensorAcc): touch = normal force on the claw, force = interaction
-  //      force on the tarsus from its parent, in the tarsus site frame
+  //      force on the tarsus from its parent, in the tarsus site frame.  Only the linear part of the spatial force is
+  //      needed: m (a_lin + alpha x r + w x (v_lin + w x r)) with r = CoM - origin.
   {
+    const int depth = l_depth(c), parent = l_parent(c), ndof = l_ndof(c);
+    const int nchild = (int)(c.lkids >> 24), ch0 = (int)(c.lkids & 0xffu), ch1 = (int)((c.lkids >> 8) & 0xffu), ch2 = (int)((c.lkids >> 16) & 0xffu);
     V3 fext = {0.f, 0.f, 0.f};
     float touch = 0.f;
     for (int k = 0; k < nc; k++) {
@@ -1003,59 +1006,70 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         if (f0 > 0.f) touch += f0;
       }
     }
-    S6 cacc2 = zero6();
+    S6 dacc = zero6();  // sum over the ancestors' dofs of cdof * qacc
 #pragma unroll 1
     for (int d = 1; d <= M.maxdepth; d++) {
-      if (c.depth == d) {
-        S6 pa = {0.f, 0.f, 0.f, 0.f, 0.f, (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz};
-        if (c.parent >= 0) pa = ld6(T.lk[c.parent]);
+      if (depth == d) {
+        S6 pa = zero6();
+        if (parent >= 0) pa = ld6(T.lk[parent]);
 #pragma unroll
-        for (int s = 0; s < 3; s++) if (s < c.ndof) pa = pa + c.v[s] * c.cdd[s] + qacc[s] * c.cdof[s];
-        cacc2 = pa;
+        for (int s = 0; s < 3; s++) if (s < ndof) pa = pa + a[s] * ld6(T.C[c.sdof[s]]);
+        dacc = pa;
         st6(T.lk[lane], pa);
       }
       DM_SYNC();
     }
-    const S6 t1 = mul_inert(c.cinert, cacc2), t2 = mul_inert(c.cinert, c.cvel);
-    V3 fint = lin(t1) + lin(cross_force(c.cvel, t2)) - fext;
+    const S6 cacc = c.caccb + dacc;
+    const V3 r = c.xip - V3{M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
+    const V3 w = ang(c.cvel);
+    V3 fint = c.mass * (lin(cacc) + cross(ang(cacc), r) + cross(w, lin(c.cvel) + cross(w, r))) - fext;
 #pragma unroll 1
     for (int d = M.maxdepth; d >= 1; d--) {
-      if (c.depth == d) {
-        if (c.nchild > 0) { const float *p = T.lk[c.ch0]; fint = fint + V3{p[0], p[1], p[2]}; }
-        if (c.nchild > 1) { const float *p = T.lk[c.ch1]; fint = fint + V3{p[0], p[1], p[2]}; }
-        if (c.nchild > 2) { const float *p = T.lk[c.ch2]; fint = fint + V3{p[0], p[1], p[2]}; }
+      if (depth == d) {
+        if (nchild > 0) { const float *p = T.lk[ch0]; fint = fint + V3{p[0], p[1], p[2]}; }
+        if (nchild > 1) { const float *p = T.lk[ch1]; fint = fint + V3{p[0], p[1], p[2]}; }
+        if (nchild > 2) { const float *p = T.lk[ch2]; fint = fint + V3{p[0], p[1], p[2]}; }
         float *o = T.lk[lane];
         o[0] = fint.x; o[1] = fint.y; o[2] = fint.z;
       }
       DM_SYNC();
     }
-    if (M.l_force[lane] >= 0) {
+    const int fi = M.l_force[lane], ti = M.l_touch[lane];
+    if (fi >= 0) {
       const Q4 sq = qmul(c.xq, Q4{M.l_fsite[0][lane], M.l_fsite[1][lane], M.l_fsite[2][lane], M.l_fsite[3][lane]});
       const V3 fl_ = mtv(q2m(sq), fint);
-      const int o = 3 * M.l_force[lane];
-      T.sens[o] += fl_.x; T.sens[o + 1] += fl_.y; T.sens[o + 2] += fl_.z;
+      T.sens[3 * fi] += fl_.x; T.sens[3 * fi + 1] += fl_.y; T.sens[3 * fi + 2] += fl_.z;
     }
-    if (M.l_touch[lane] >= 0) T.sens[18 + M.l_touch[lane]] += touch;
+    if (ti >= 0) T.sens[18 + ti] += touch;
     DM_SYNC();
   }
   if (!integrate) return;  // mj_forward: state untouched
-  // ---- integrate
+  // ---- Euler with implicit joint damping (mj: mj_Euler): (M + h B) qacc_e = qfrc_smooth + qfrc_constraint
+  float damp[3];
   bool any_damp = false;
 #pragma unroll
-  for (int s = 0; s < 4; s++) any_damp |= slot_on(c, s) && c.damp[s] > 0.f && !(c.flags & BF_NO_DAMPER);
-  float qe[4];
+  for (int s = 0; s < 3; s++) {
+    damp[s] = (slot_on(c, s) && !(c.flags & BF_NO_DAMPER)) ? M.s_damp[s][lane] : 0.f;
+    any_damp |= damp[s] > 0.f;
+  }
+  float qe[3];
   if (__any(any_damp)) {
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      if (slot_on(c, s)) { T.dadd[c.sdof[s]] = h * damp[s]; T.X4[c.sdof[s]] = make_float4(qs[s] + qc[s], 0.f, 0.f, 0.f); }
+    }
+    DM_SYNC();
     factor(c, T.Mq, true, T.Lh, T.dinv_h);
     solve4(c, T.Lh, T.dinv_h);
 #pragma unroll
-    for (int s = 0; s < 4; s++) qe[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
+    for (int s = 0; s < 3; s++) qe[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
   } else {
 #pragma unroll
-    for (int s = 0; s < 4; s++) qe[s] = qacc[s];
+    for (int s = 0; s < 3; s++) qe[s] = a[s];
   }
   DM_SYNC();
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  for (int s = 0; s < 3; s++) {
     if (slot_on(c, s)) { c.v[s] += h * qe[s]; c.q[s] += h * c.v[s]; }
   }
   // ball: no damping, so its Euler acceleration is ab = (tau_smooth + J_b' f) / I
@@ -1080,36 +1094,19 @@ __global__ __launch_bounds__(64, 1) void ball_step_kernel(const BallModel *__res
   BState &S = states[env];
   Ctx c;
   c.M = Mp; c.T = &T; c.lane = lane; c.flags = K.flags;
-  c.parent = M.l_parent[lane]; c.depth = M.l_depth[lane]; c.nchild = M.l_nchild[lane];
-  c.ch0 = M.l_child[0][lane]; c.ch1 = M.l_child[1][lane]; c.ch2 = M.l_child[2][lane]; c.ndof = M.l_ndof[lane];
-  c.pos = {M.l_pos[0][lane], M.l_pos[1][lane], M.l_pos[2][lane]};
-  c.quat = {M.l_quat[0][lane], M.l_quat[1][lane], M.l_quat[2][lane], M.l_quat[3][lane]};
-  c.ipos = {M.l_ipos[0][lane], M.l_ipos[1][lane], M.l_ipos[2][lane]};
-  c.iquat = {M.l_iquat[0][lane], M.l_iquat[1][lane], M.l_iquat[2][lane], M.l_iquat[3][lane]};
-  c.inertia = {M.l_inertia[0][lane], M.l_inertia[1][lane], M.l_inertia[2][lane]};
-  c.mass = M.l_mass[lane];
-#pragma unroll
-  for (int k = 0; k < 8; k++) c.fl[k] = M.l_fl[k][lane];
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const int f = M.s_dof[s][lane];
-    c.sdof[s] = f;
-    c.sblk[s] = f >= 0 ? M.d_blk[f] : 0; c.sli[s] = f >= 0 ? M.d_li[f] : 0; c.slim[s] = M.s_limited[s][lane];
-    c.stiff[s] = M.s_stiff[s][lane]; c.sref[s] = M.s_sref[s][lane]; c.damp[s] = M.s_damp[s][lane];
-    c.lo[s] = M.s_lo[s][lane]; c.hi[s] = M.s_hi[s][lane]; c.invw[s] = M.s_invw[s][lane]; c.sK[s] = M.s_K[s][lane]; c.sB[s] = M.s_B[s][lane];
-  }
+  c.lpack = M.l_pack[lane]; c.lkids = M.l_kids[lane]; c.xh = M.x_on[lane];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
-    c.axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
-    c.jpos[s] = {M.s_jpos[0][s][lane], M.s_jpos[1][s][lane], M.s_jpos[2][s][lane]};
+    const int f = M.s_dof[s][lane];
+    c.sdof[s] = f;
+    c.sbl[s] = f >= 0 ? ((unsigned)M.d_blk[f] | ((unsigned)M.d_li[f] << 8)) : 0u;
   }
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
-    c.emeta[t] = M.e_meta[t][lane];
-    c.eadr[t] = (unsigned)M.e_adr[t][lane] | ((unsigned)M.e_fmask[t][lane] << 16);
-    const unsigned i = c.emeta[t] & 0xffu;
-    c.estep[t] = (unsigned)M.e_rowstep[t][lane] | ((unsigned)M.e_colstep[t][lane] << 8) | ((unsigned)(unsigned short)M.d_madr[i < ND ? i : 0] << 16);
+    c.e0[t] = M.e_meta[t][lane];
+    c.e1[t] = (unsigned)M.e_adr[t][lane] | ((unsigned)M.e_fmask[t][lane] << 10) | ((unsigned)M.e_rowstep[t][lane] << 24) | ((unsigned)M.e_colstep[t][lane] << 28);
   }
+  for (int k = lane; k < NSTEP * 16; k += 64) T.piv[k / 16][k % 16] = M.piv[k / 16][k % 16];
   const bool do_reset = (mode == 1) || (mode == 0 && S.needs_reset != 0);
   const bool phys_only = (mode == 2);
   float act_reg = 0.f, ctrl_reg = 0.f;
@@ -1117,15 +1114,15 @@ __global__ __launch_bounds__(64, 1) void ball_step_kernel(const BallModel *__res
   if (do_reset) {
     // ref: walk_on_ball.py:52-54 + fruitfly.py:330-340: qpos0, zero velocity / activation, wings folded to their spring reference
 #pragma unroll
-    for (int s = 0; s < 4; s++) { c.q[s] = 0.f; c.v[s] = 0.f; }
+    for (int s = 0; s < 3; s++) { c.q[s] = 0.f; c.v[s] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < 3; s++)
       if (slot_on(c, s)) for (int w = 0; w < M.nwing; w++) if (M.wing_dof[w] == c.sdof[s]) c.q[s] = M.qspring[c.sdof[s]];
     c.bq = {1.f, 0.f, 0.f, 0.f}; c.bw = {0.f, 0.f, 0.f};
     step_counter = 0;
   } else {
 #pragma unroll
-    for (int s = 0; s < 4; s++) { c.q[s] = slot_on(c, s) ? S.q[c.sdof[s]] : 0.f; c.v[s] = slot_on(c, s) ? S.v[c.sdof[s]] : 0.f; }
+    for (int s = 0; s < 3; s++) { c.q[s] = slot_on(c, s) ? S.q[c.sdof[s]] : 0.f; c.v[s] = slot_on(c, s) ? S.v[c.sdof[s]] : 0.f; }
     c.bq = {S.ballq[0], S.ballq[1], S.ballq[2], S.ballq[3]}; c.bw = {S.ballw[0], S.ballw[1], S.ballw[2]};
     act_reg = lane < NU ? S.act[lane] : 0.f;
     if (lane < NU) {
@@ -1148,26 +1145,22 @@ __global__ __launch_bounds__(64, 1) void ball_step_kernel(const BallModel *__res
   DM_SYNC();
   const int nsub = phys_only ? nphys : M.nsub;
   float qn2 = 0.f;
-  stage1(c);
-  if (do_reset) {
-    // mj_forward after the reset with actuation disabled (dm_control's after_reset); its sensors are the first sample
-    float dummy;
-    const int saved = c.flags;
-    c.flags |= BF_NO_ACTUATION;
-    stage2(c, 0.f, 0.f, dummy, false, iters, &qn2);
-    c.flags = saved;
-  } else {
+  // one copy of each stage: stage1 ; [stage2 ; stage1] x nsub.  A reset is stage1 ; stage2 without actuation and without
+  // integrating (mj_forward, dm_control's after_reset); its sensors are the first sample of the buffers.
+  if (do_reset) c.flags |= BF_NO_ACTUATION;
 #pragma unroll 1
-    for (int s = 0; s < nsub; s++) {
-      float act_new;
-      stage2(c, act_reg, ctrl_reg, act_new, true, iters, &qn2);
-      act_reg = act_new;
-      stage1(c);
-    }
+  for (int s = 0;; s++) {
+    stage1(c);
+    if (!do_reset && s == nsub) break;
+    float act_new;
+    stage2(c, act_reg, ctrl_reg, act_new, !do_reset, iters, &qn2);
+    if (do_reset) break;
+    act_reg = act_new;
   }
+  c.flags = K.flags;
   // ---- store state
 #pragma unroll
-  for (int s = 0; s < 4; s++) if (slot_on(c, s)) { S.q[c.sdof[s]] = c.q[s]; S.v[c.sdof[s]] = c.v[s]; }
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { S.q[c.sdof[s]] = c.q[s]; S.v[c.sdof[s]] = c.v[s]; }
   if (lane < NU) S.act[lane] = do_reset ? 0.f : act_reg;
   if (lane == 0) {
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
@@ -1178,7 +1171,7 @@ __global__ __launch_bounds__(64, 1) void ball_step_kernel(const BallModel *__res
   // ---- observation (ref: SURVEY App. A order): accelerometer 3 | actuator_activation 59 | appendages_pos 21 | ball_qvel 3 |
   //      force 18 | gyro 3 | joints_pos 85 | joints_vel 85 | touch 6 | velocimeter 3 | world_zaxis 3
 #pragma unroll
-  for (int s = 0; s < 4; s++) if (slot_on(c, s)) { T.Q[c.sdof[s]] = c.q[s]; T.V[c.sdof[s]] = c.v[s]; }
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { T.Q[c.sdof[s]] = c.q[s]; T.V[c.sdof[s]] = c.v[s]; }
   {
     float *o = T.lk[lane];
     o[0] = c.xp.x; o[1] = c.xp.y; o[2] = c.xp.z; o[3] = c.xq.w; o[4] = c.xq.x; o[5] = c.xq.y; o[6] = c.xq.z;

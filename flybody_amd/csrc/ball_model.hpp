@@ -69,6 +69,7 @@ struct BallModel {
   float s_actcoef[2][4][NL];
   // halteres (lanes 0, 1): constant inertia, gravity torque Gc cos q + Gs sin q, drag -cv qd - cq |qd| qd
   float x_M[NL], x_Gc[NL], x_Gs[NL], x_cv[NL], x_cq[NL];
+  int x_on[NL];  // lane carries a haltere in slot 2
   // ---- ball
   float b_I, b_center[3], b_radius, b_iquat[4], b_fl[8], b_fric, b_K_unused;
   // ---- joint-space inertia structure (fly dofs)
@@ -94,6 +95,8 @@ struct BallModel {
   float act_lo[NL], act_hi[NL];
   float meaninertia;
   int noslip_iterations;
+  float j_solimp[5], c_solimp[5];  // joint-limit / ball-contact impedance parameters (uniform over the model; checked on the host)
+  unsigned l_pack[NL], l_kids[NL];  // parent+1 | depth << 8 | ndof << 12 ;  child0 | child1 << 8 | child2 << 16 | nchild << 24
 };
 
 namespace detail {
@@ -257,9 +260,14 @@ inline BallHost build_ball_model(const Blob &b) {
     }
   }
   // ---- halteres: closed-form single hinge on the fixed thorax
-  for (int x = 0; x < 2; x++) {
-    int i = halt[x], j = bjadr.i(i), od = jdadr.i(j);
-    fill_slot(3, x, j);
+  int hl[2] = {-1, -1};
+  for (int l = 0, k = 0; l < NL && k < 2; l++) if (M.l_ndof[l] <= 2) hl[k++] = l;
+  if (hl[1] < 0) throw std::runtime_error("ball model: no free dof slot for the halteres");
+  for (int xx = 0; xx < 2; xx++) {
+    const int x = hl[xx];
+    int i = halt[xx], j = bjadr.i(i), od = jdadr.i(j);
+    fill_slot(2, x, j);
+    M.x_on[x] = 1;
     double pos[3] = {bpos.f(3 * i), bpos.f(3 * i + 1), bpos.f(3 * i + 2)}, quat[4] = {bquat.f(4 * i), bquat.f(4 * i + 1), bquat.f(4 * i + 2), bquat.f(4 * i + 3)};
     double wq[4], ax_b[3] = {jaxis.f(3 * j), jaxis.f(3 * j + 1), jaxis.f(3 * j + 2)}, jp[3] = {jpos.f(3 * j), jpos.f(3 * j + 1), jpos.f(3 * j + 2)};
     (void)pos;
@@ -316,7 +324,7 @@ inline BallHost build_ball_model(const Blob &b) {
     M.d_amask[f] = (unsigned short)amask[f]; M.d_arm[f] = (float)darm.f(f + 3);
   }
   if (nblk > NBLK || adr > NMMAX) throw std::runtime_error("ball model: inertia structure exceeds capacities");
-  for (int x = 0; x < 2; x++) M.d_arm[M.s_dof[3][x]] = 0.f;  // x_M already holds the haltere armature
+  for (int l = 0; l < NL; l++) if (M.x_on[l]) M.d_arm[M.s_dof[2][l]] = 0.f;  // x_M already holds the haltere armature
   M.nM = adr; M.nblk = nblk;
   blk_start.push_back(ND);
   for (int s = 0; s < NSTEP; s++) for (int bb = 0; bb < NBLK + 4; bb++) { M.piv[s][bb] = 0xffffffffu; M.piv_dof[s][bb] = 255; }
@@ -458,6 +466,20 @@ inline BallHost build_ball_model(const Blob &b) {
   if ((int)so.f(0) != 1) throw std::runtime_error("ball model: elliptic cones expected");
   if (so.f(2) != 1.0) throw std::runtime_error("ball model: impratio != 1 unsupported");
   M.noslip_iterations = (int)so.f(1);
+  for (int k = 0; k < 5; k++) { M.j_solimp[k] = (float)jsolimp.f(k); M.c_solimp[k] = -1.f; }
+  for (int j = 0; j < njnt; j++) for (int k = 0; k < 5; k++)
+    if (jtype.i(j) == 3 && jsolimp.f(5 * j + k) != jsolimp.f(k)) throw std::runtime_error("ball model: joint solimp is expected to be uniform");
+  for (int l = 0; l < NL; l++) {
+    if (!M.g_has[l]) continue;
+    for (int k = 0; k < 5; k++) {
+      if (M.c_solimp[k] < 0) M.c_solimp[k] = M.g_solimp[k][l];
+      else if (M.c_solimp[k] != M.g_solimp[k][l]) throw std::runtime_error("ball model: contact solimp is expected to be uniform");
+    }
+  }
+  for (int l = 0; l < NL; l++) {
+    M.l_pack[l] = (unsigned)(M.l_parent[l] + 1) | ((unsigned)M.l_depth[l] << 8) | ((unsigned)M.l_ndof[l] << 12);
+    M.l_kids[l] = (unsigned)M.l_child[0][l] | ((unsigned)M.l_child[1][l] << 8) | ((unsigned)M.l_child[2][l] << 16) | ((unsigned)M.l_nchild[l] << 24);
+  }
   (void)dbody; (void)djnt; (void)gcondim;
   return H;
 }
