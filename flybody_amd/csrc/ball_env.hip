@@ -28,6 +28,13 @@ using namespace dm;
 
 enum { BF_NO_FLUID = 1, BF_NO_LIMIT = 2, BF_NO_DAMPER = 4, BF_NO_SPRING = 8, BF_NO_GRAVITY = 16, BF_NO_ACTUATION = 32,
        BF_NO_CONTACT = 64, BF_NO_NOSLIP = 128, BF_NO_ADHESION = 256 };
+// Keeps the fully unrolled per-entry loops from being interleaved into one huge basic block of loads: without it the
+// scheduler hoists every entry's LDS reads to the top and the kernel needs > 500 VGPRs.
+#define ENTRY_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Loop-invariant code motion otherwise precomputes every LDS address derived from the per-lane entry / slot words once per
+// launch and keeps ~150 of them alive across the substep loop; an opaque copy forces the (cheap) address math to stay local.
+__device__ __forceinline__ unsigned opq(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opq(int x) { asm volatile("" : "+v"(x)); return x; }
 constexpr int kMaxNewton = 12;
 constexpr int kLsIter = 14;
 
@@ -83,7 +90,6 @@ struct Ctx {
   Q4 bq;
   V3 bw, btau;
   int nc;
-  unsigned e0[ECAP], e1[ECAP];  // e0: i | j << 8 | li_i << 16 | li_j << 20 | blk << 24 | valid << 31;  e1: adr | fmask << 10 | rowstep << 24 | colstep << 28
 };
 
 __device__ __forceinline__ bool slot_on(const Ctx &c, int s) { return c.sdof[s] >= 0; }
@@ -97,94 +103,100 @@ __device__ __forceinline__ const BallModel &model(const Ctx &c) {
 }
 
 // ------------------------------------------------------------------------------------------------ block factorisation
-// mj: mj_factorI restricted to M's 12 independent blocks, all blocks in lock step: at step s every block eliminates its
-// s-th pivot from the leaf end; an entry (i, j) is touched when i is a proper ancestor of that pivot k:
-//   L[i][j] -= L[k][i] * L[k][j] / L[k][k]   (all values unscaled until the final pass, exactly as mj_factorI orders it)
-// `src` + diag(dadd) is factorised into `dst`; dinv receives 1 / D.
+// mj: mj_factorI on M's 12 independent blocks, all blocks in lock step (step s eliminates every block's s-th pivot from the
+// leaf end).  The matrix lives in LDS, so any lane can apply any update: the host lays the ~2300 updates
+//   L[e] -= L[ki] * L[kj] / L[kk]        (e = (i, j), i a proper ancestor of the pivot k; values stay unscaled until the end)
+// out in step order as `nfs` slots of 64 independent updates (ball_model.hpp), read coalesced and one slot ahead.
+// LDS operations of a wave complete in issue order, which is all the ordering the steps need.
 __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, float *dst, float *dinv) {
   BTile &T = *c.T;
-#pragma unroll
+  const BallModel &M = model(c);
+  const int lane = c.lane;
+#pragma unroll 2
   for (int t = 0; t < ECAP; t++) {
-    if (c.e0[t] >> 31) {
-      const unsigned adr = c.e1[t] & 0x3ffu, i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
+    const unsigned ea = M.ent_a[t][lane];
+    if (ea >> 31) {
+      const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu, adr = (ea >> 16) & 0x3ffu;
       float vv = src[adr];
       if (use_add && i == j) vv += T.dadd[i];
       dst[adr] = vv;
     }
   }
   DM_SYNC();
+  const int nfs = M.nfs;
+  unsigned na = M.fac_a[0][lane], nb = M.fac_b[0][lane];
 #pragma unroll 1
-  for (int s = 0; s < NSTEP - 1; s++) {
-#pragma unroll
-    for (int t = 0; t < ECAP; t++) {
-      if ((c.e1[t] >> (10 + s)) & 1u) {
-        const unsigned meta = c.e0[t], blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu, lij = (meta >> 20) & 0xfu;
-        const unsigned p = T.piv[s][blk], mk = p & 0xffffu, am = p >> 16;
-        const unsigned oi = __popc(am & ~((2u << lii) - 1u)), oj = __popc(am & ~((2u << lij) - 1u));
-        const float lkk = dst[mk], lki = dst[mk + oi], lkj = dst[mk + oj];
-        const unsigned adr = c.e1[t] & 0x3ffu;
-        dst[adr] -= lki * lkj / lkk;
-      }
+  for (int slot = 0; slot < nfs; slot++) {
+    const unsigned a = na, b = nb;
+    if (slot + 1 < nfs) { na = M.fac_a[slot + 1][lane]; nb = M.fac_b[slot + 1][lane]; }
+    if (a >> 31) {
+      const float lkk = dst[(a >> 10) & 0x3ffu], lki = dst[(a >> 20) & 0x3ffu], lkj = dst[b & 0x3ffu];
+      dst[a & 0x3ffu] -= lki * lkj / lkk;
     }
     DM_SYNC();
   }
-#pragma unroll
+#pragma unroll 2
   for (int t = 0; t < ECAP; t++) {
-    if (c.e0[t] >> 31) {
-      const unsigned i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
-      if (i == j) dinv[i] = 1.f / dst[c.e1[t] & 0x3ffu];
-    }
+    const unsigned ea = M.ent_a[t][lane];
+    if ((ea >> 31) && (ea & 0xffu) == ((ea >> 8) & 0xffu)) dinv[ea & 0xffu] = 1.f / dst[(ea >> 16) & 0x3ffu];
   }
   DM_SYNC();
-#pragma unroll
+#pragma unroll 2
   for (int t = 0; t < ECAP; t++) {
-    if (c.e0[t] >> 31) {
-      const unsigned i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
-      if (i != j) dst[c.e1[t] & 0x3ffu] *= dinv[i];
-    }
+    const unsigned ea = M.ent_a[t][lane];
+    if ((ea >> 31) && (ea & 0xffu) != ((ea >> 8) & 0xffu)) dst[(ea >> 16) & 0x3ffu] *= dinv[ea & 0xffu];
   }
   DM_SYNC();
 }
 
-// mj: mj_solveLD on T.X4 (four right-hand sides at once), blocks in lock step: rows leaf -> root, D^-1, columns root -> leaf
+// mj: mj_solveLD on T.X4 (four right-hand sides at once): rows leaf -> root, D^-1, columns root -> leaf, from the two
+// schedules p1 / p2 (slots of 64 independent updates in step order)
 __device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv) {
   BTile &T = *c.T;
+  const BallModel &M = model(c);
+  const int lane = c.lane;
+  {
+    const int n = M.np1;
+    unsigned nw = M.p1[0][lane];
 #pragma unroll 1
-  for (int s = 0; s < NSTEP - 1; s++) {
-#pragma unroll
-    for (int t = 0; t < ECAP; t++) {
-      const unsigned meta = c.e0[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
-      if ((meta >> 31) && i != j && ((c.e1[t] >> 24) & 0xfu) == (unsigned)s) {
-        const float l = L[c.e1[t] & 0x3ffu];
+    for (int slot = 0; slot < n; slot++) {
+      const unsigned w = nw;
+      if (slot + 1 < n) nw = M.p1[slot + 1][lane];
+      if (w >> 31) {
+        const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
+        const float l = L[w & 0x3ffu];
         const float4 xi = T.X4[i];
         float4 xj = T.X4[j];
         xj.x -= l * xi.x; xj.y -= l * xi.y; xj.z -= l * xi.z; xj.w -= l * xi.w;
         T.X4[j] = xj;
       }
+      DM_SYNC();
     }
-    DM_SYNC();
   }
-  for (int f = c.lane; f < ND; f += 64) {
+  for (int f = lane; f < ND; f += 64) {
     const float dv = dinv[f];
     float4 x = T.X4[f];
     x.x *= dv; x.y *= dv; x.z *= dv; x.w *= dv;
     T.X4[f] = x;
   }
   DM_SYNC();
+  {
+    const int n = M.np2;
+    unsigned nw = M.p2[0][lane];
 #pragma unroll 1
-  for (int r = 0; r < NSTEP - 1; r++) {
-#pragma unroll
-    for (int t = 0; t < ECAP; t++) {
-      const unsigned meta = c.e0[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu;
-      if ((meta >> 31) && i != j && (c.e1[t] >> 28) == (unsigned)r) {
-        const float l = L[c.e1[t] & 0x3ffu];
+    for (int slot = 0; slot < n; slot++) {
+      const unsigned w = nw;
+      if (slot + 1 < n) nw = M.p2[slot + 1][lane];
+      if (w >> 31) {
+        const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
+        const float l = L[w & 0x3ffu];
         const float4 xj = T.X4[j];
         float4 xi = T.X4[i];
         xi.x -= l * xj.x; xi.y -= l * xj.y; xi.z -= l * xj.z; xi.w -= l * xj.w;
         T.X4[i] = xi;
       }
+      DM_SYNC();
     }
-    DM_SYNC();
   }
 }
 
@@ -338,17 +350,18 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   // ---- mj: mj_crb joint-space inertia, one entry per (lane, slot t)
 #pragma unroll
   for (int s = 0; s < 3; s++) {
-    if (s < ndof) { st6(T.F[c.sdof[s]], mul_inert(crb, cdof[s])); st6(T.C[c.sdof[s]], cdof[s]); }
+    if (s < ndof) { st6(T.F[opq(c.sdof[s])], mul_inert(crb, cdof[s])); st6(T.C[opq(c.sdof[s])], cdof[s]); }
   }
   if (c.xh) { st6(T.F[c.sdof[2]], S6{M.x_M[lane], 0.f, 0.f, 0.f, 0.f, 0.f}); st6(T.C[c.sdof[2]], S6{1.f, 0.f, 0.f, 0.f, 0.f, 0.f}); }
   DM_SYNC();
-#pragma unroll
+#pragma unroll 2
   for (int t = 0; t < ECAP; t++) {
-    if (c.e0[t] >> 31) {
-      const unsigned i = c.e0[t] & 0xffu, j = (c.e0[t] >> 8) & 0xffu;
+    const unsigned ea = M.ent_a[t][lane];
+    if (ea >> 31) {
+      const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu;
       float mij = dot6(ld6(T.C[j]), ld6(T.F[i]));
       if (i == j) mij += M.d_arm[i];
-      T.Mq[c.e1[t] & 0x3ffu] = mij;
+      T.Mq[(ea >> 16) & 0x3ffu] = mij;
     }
   }
   DM_SYNC();
@@ -483,7 +496,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
   const V3 bc = {M.b_center[0], M.b_center[1], M.b_center[2]};
 #pragma unroll
-  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { T.Q[c.sdof[s]] = c.q[s]; T.V[c.sdof[s]] = c.v[s]; }
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { T.Q[opq(c.sdof[s])] = c.q[s]; T.V[opq(c.sdof[s])] = c.v[s]; }
   DM_SYNC();
   // ---- mj: mj_fwdActuation: first-order activation filter, affine position servo on the activation
   float act_dot = 0.f;
@@ -563,9 +576,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       const int a0 = M.s_act[0][s][lane], a1 = M.s_act[1][s][lane];
       if (a0 >= 0) f += M.s_actcoef[0][s][lane] * T.frc[a0];
       if (a1 >= 0) f += M.s_actcoef[1][s][lane] * T.frc[a1];
-      if (nc) f += contact_gather(c, c.sbl[s], T.c_w);
+      if (nc) f += contact_gather(c, opq(c.sbl[s]), T.c_w);
       qs[s] = f;
-      T.X4[c.sdof[s]] = make_float4(f, 0.f, 0.f, 0.f);
+      T.X4[opq(c.sdof[s])] = make_float4(f, 0.f, 0.f, 0.f);
     }
   }
   V3 qsb = c.btau;
@@ -575,7 +588,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   DM_SYNC();
   solve4(c, T.Lm, T.dinv_m);
 #pragma unroll
-  for (int s = 0; s < 3; s++) am[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
+  for (int s = 0; s < 3; s++) am[s] = slot_on(c, s) ? T.X4[opq(c.sdof[s])].x : 0.f;
   const float Ib = M.b_I;
   const V3 amb = (1.f / Ib) * qsb;
   // ---- joint-limit rows (mj: mj_instantiateLimit, margin 0): sign, D, aref per slot
@@ -613,7 +626,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     for (int it = 0; it < kMaxNewton; it++) {
       // contact residuals, forces, local Hessians (lane = contact)
 #pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = a[s];
       DM_SYNC();
       if (lane < nc) {
         const int nch = T.c_nch[lane];
@@ -653,9 +666,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
             if (r < 0.f) { lf[s] = -lD[s] * r; gg -= lsgn[s] * lf[s]; hadd[s] = lD[s]; }
           }
           if (nc) {
-            gg -= contact_gather(c, c.sbl[s], T.c_f);
-            const int blk = (int)(c.sbl[s] & 0xffu);
-            const unsigned li = c.sbl[s] >> 8;
+            gg -= contact_gather(c, opq(c.sbl[s]), T.c_f);
+            const int blk = (int)(opq(c.sbl[s]) & 0xffu);
+            const unsigned li = opq(c.sbl[s]) >> 8;
             for (int k = 0; k < nc; k++) {
               if (T.c_blk[k] == blk && ((T.c_amask[k] >> li) & 1u)) {
                 const int p = __popc(T.c_amask[k] & ((1u << li) - 1u));
@@ -667,7 +680,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           }
           g[s] = gg;
           gn2 += gg * gg; fn2 += Ma[s] * Ma[s] + qs[s] * qs[s];
-          T.dadd[c.sdof[s]] = hadd[s];
+          T.dadd[opq(c.sdof[s])] = hadd[s];
         }
       }
       V3 gb = Ib * ab - qsb;
@@ -692,11 +705,11 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       iters++;
       // H_ff = M + diag(limit D) + sum_c J_f' Hc J_f  (same sparsity as M: a contact row only spans one chain)
       DM_SYNC();
-#pragma unroll
+#pragma unroll 1
       for (int t = 0; t < ECAP; t++) {
-        if (c.e0[t] >> 31) {
-          const unsigned meta = c.e0[t], i = meta & 0xffu, j = (meta >> 8) & 0xffu, blk = (meta >> 24) & 0xfu, lii = (meta >> 16) & 0xfu,
-                         lij = (meta >> 20) & 0xfu, adr = c.e1[t] & 0x3ffu;
+        const unsigned ea = M.ent_a[t][lane], eb = M.ent_b[t][lane];
+        if (ea >> 31) {
+          const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu, adr = (ea >> 16) & 0x3ffu, blk = eb & 0xfu, lii = (eb >> 4) & 0xfu, lij = (eb >> 8) & 0xfu;
           float hv = T.Mq[adr];
           if (i == j) hv += T.dadd[i];
           for (int k = 0; k < nc; k++) {
@@ -713,7 +726,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       factor(c, T.Lh, false, T.Lh, T.dinv_h);
       // [ -g_f | H_fb ] through H_ff^-1, then the 3x3 Schur complement on the ball
 #pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = make_float4(-g[s], hfb[s][0], hfb[s][1], hfb[s][2]);
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(-g[s], hfb[s][0], hfb[s][1], hfb[s][2]);
       DM_SYNC();
       solve4(c, T.Lh, T.dinv_h);
       float4 xs[3];
@@ -722,7 +735,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       for (int s = 0; s < 3; s++) {
         xs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot_on(c, s)) {
-          xs[s] = T.X4[c.sdof[s]];
+          xs[s] = T.X4[opq(c.sdof[s])];
           sc[0] += hfb[s][0] * xs[s].y; sc[1] += hfb[s][0] * xs[s].z; sc[2] += hfb[s][0] * xs[s].w;
           sc[3] += hfb[s][1] * xs[s].z; sc[4] += hfb[s][1] * xs[s].w; sc[5] += hfb[s][2] * xs[s].w;
           sc[6] += hfb[s][0] * xs[s].x; sc[7] += hfb[s][1] * xs[s].x; sc[8] += hfb[s][2] * xs[s].x;
@@ -745,7 +758,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       for (int s = 0; s < 3; s++) dd[s] = xs[s].x - xs[s].y * db.x - xs[s].z * db.y - xs[s].w * db.z;
       // jd = J d per row; Md = -g - (H - M) d
 #pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = dd[s];
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = dd[s];
       DM_SYNC();
       if (lane < nc) {
         const int nch = T.c_nch[lane];
@@ -769,7 +782,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         Md[s] = 0.f;
         if (slot_on(c, s)) {
           float md = -g[s] - hadd[s] * dd[s];
-          if (nc) md -= contact_gather(c, c.sbl[s], T.c_w);
+          if (nc) md -= contact_gather(c, opq(c.sbl[s]), T.c_w);
           Md[s] = md;
           c0s += (Ma[s] - qs[s]) * dd[s]; c1s += md * dd[s];
         }
@@ -823,7 +836,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
     // final forces at the solution
 #pragma unroll
-    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x = a[s];
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = a[s];
     DM_SYNC();
     if (lane < nc) {
       float jar[3];
@@ -855,8 +868,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 #pragma unroll
     for (int s = 0; s < 3; s++) {
       if (slot_on(c, s)) {
-        float f = lsgn[s] * lf[s] + contact_gather(c, c.sbl[s], T.c_w);
-        T.X4[c.sdof[s]] = make_float4(f, 0.f, 0.f, 0.f);
+        float f = lsgn[s] * lf[s] + contact_gather(c, opq(c.sbl[s]), T.c_w);
+        T.X4[opq(c.sdof[s])] = make_float4(f, 0.f, 0.f, 0.f);
       }
     }
     V3 w0b = {0.f, 0.f, 0.f};
@@ -868,7 +881,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     solve4(c, T.Lm, T.dinv_m);
     // b' = J_t (a_smooth + w0) - aref_t  (lane = tangential row)
 #pragma unroll
-    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]].x += am[s];
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x += am[s];
     DM_SYNC();
     float brow = 0.f;
     if (lane < nr) {
@@ -964,7 +977,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     qc[s] = 0.f;
     if (slot_on(c, s)) {
       qc[s] = lsgn[s] * lf[s];
-      if (nc) qc[s] += contact_gather(c, c.sbl[s], T.c_f);
+      if (nc) qc[s] += contact_gather(c, opq(c.sbl[s]), T.c_f);
     }
   }
   V3 qcb = {0.f, 0.f, 0.f};
@@ -976,11 +989,11 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   if (did_noslip) {  // qacc = a_s + M^-1 J' f with the swept forces
 #pragma unroll
-    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[c.sdof[s]] = make_float4(qc[s], 0.f, 0.f, 0.f);
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(qc[s], 0.f, 0.f, 0.f);
     DM_SYNC();
     solve4(c, T.Lm, T.dinv_m);
 #pragma unroll
-    for (int s = 0; s < 3; s++) a[s] = slot_on(c, s) ? am[s] + T.X4[c.sdof[s]].x : 0.f;
+    for (int s = 0; s < 3; s++) a[s] = slot_on(c, s) ? am[s] + T.X4[opq(c.sdof[s])].x : 0.f;
     ab = amb + (1.f / Ib) * qcb;
     DM_SYNC();
   }
@@ -1013,7 +1026,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         S6 pa = zero6();
         if (parent >= 0) pa = ld6(T.lk[parent]);
 #pragma unroll
-        for (int s = 0; s < 3; s++) if (s < ndof) pa = pa + a[s] * ld6(T.C[c.sdof[s]]);
+        for (int s = 0; s < 3; s++) if (s < ndof) pa = pa + a[s] * ld6(T.C[opq(c.sdof[s])]);
         dacc = pa;
         st6(T.lk[lane], pa);
       }
@@ -1056,13 +1069,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   if (__any(any_damp)) {
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-      if (slot_on(c, s)) { T.dadd[c.sdof[s]] = h * damp[s]; T.X4[c.sdof[s]] = make_float4(qs[s] + qc[s], 0.f, 0.f, 0.f); }
+      if (slot_on(c, s)) { T.dadd[opq(c.sdof[s])] = h * damp[s]; T.X4[opq(c.sdof[s])] = make_float4(qs[s] + qc[s], 0.f, 0.f, 0.f); }
     }
     DM_SYNC();
     factor(c, T.Mq, true, T.Lh, T.dinv_h);
     solve4(c, T.Lh, T.dinv_h);
 #pragma unroll
-    for (int s = 0; s < 3; s++) qe[s] = slot_on(c, s) ? T.X4[c.sdof[s]].x : 0.f;
+    for (int s = 0; s < 3; s++) qe[s] = slot_on(c, s) ? T.X4[opq(c.sdof[s])].x : 0.f;
   } else {
 #pragma unroll
     for (int s = 0; s < 3; s++) qe[s] = a[s];
@@ -1084,7 +1097,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-__global__ __launch_bounds__(64, 1) void ball_step_kernel(const BallModel *__restrict__ Mp, BTaskDev K, BState *__restrict__ states,
+__global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__restrict__ Mp, BTaskDev K, BState *__restrict__ states,
                                                          const float *__restrict__ act, float *__restrict__ obs, float *__restrict__ rew,
                                                          float *__restrict__ disc, int *__restrict__ st, int batch, int mode, int nphys) {
   const int env = blockIdx.x, lane = threadIdx.x;
@@ -1100,11 +1113,6 @@ __global__ __launch_bounds__(64, 1) void ball_step_kernel(const BallModel *__res
     const int f = M.s_dof[s][lane];
     c.sdof[s] = f;
     c.sbl[s] = f >= 0 ? ((unsigned)M.d_blk[f] | ((unsigned)M.d_li[f] << 8)) : 0u;
-  }
-#pragma unroll
-  for (int t = 0; t < ECAP; t++) {
-    c.e0[t] = M.e_meta[t][lane];
-    c.e1[t] = (unsigned)M.e_adr[t][lane] | ((unsigned)M.e_fmask[t][lane] << 10) | ((unsigned)M.e_rowstep[t][lane] << 24) | ((unsigned)M.e_colstep[t][lane] << 28);
   }
   for (int k = lane; k < NSTEP * 16; k += 64) T.piv[k / 16][k % 16] = M.piv[k / 16][k % 16];
   const bool do_reset = (mode == 1) || (mode == 0 && S.needs_reset != 0);

@@ -44,6 +44,8 @@ constexpr int NOBSJ = 85;
 constexpr int NOBS = 289;
 constexpr int NACT = 59;
 constexpr int MAXDEPTH = 8;
+constexpr int NFS = 56;     // slots of the factorisation schedule (64 entry updates per slot)
+constexpr int NPS = 24;     // slots of each triangular-solve schedule
 
 struct BallModel {
   // ---- options
@@ -80,6 +82,12 @@ struct BallModel {
   unsigned short e_adr[ECAP][NL];   // address in the M layout
   unsigned short e_fmask[ECAP][NL]; // factor: bit s set when pivot step s updates this entry
   unsigned char e_rowstep[ECAP][NL], e_colstep[ECAP][NL];  // solve passes: the step at which the entry fires
+  // Schedules (any lane may process any entry: the matrices live in LDS).  One slot = up to 64 independent updates.
+  //   fac_a: adr_e | adr_kk << 10 | adr_ki << 20 | valid << 31, fac_b: adr_kj      L[e] -= L[ki] L[kj] / L[kk]
+  //   p1 / p2: adr_e | i << 10 | j << 17 | valid << 31                              x[j] -= L[e] x[i]  /  x[i] -= L[e] x[j]
+  //   ent_a: i | j << 8 | adr << 16 | valid << 31, ent_b: blk | li_i << 4 | li_j << 8 (assembly, final scaling)
+  unsigned fac_a[NFS][NL], fac_b[NFS][NL], p1[NPS][NL], p2[NPS][NL], ent_a[ECAP][NL], ent_b[ECAP][NL];
+  int nfs, np1, np2;
   unsigned int piv[NSTEP][NBLK + 4];  // pivot of block b at step s: madr | amask << 16 ... (0xffffffff = none)
   unsigned char piv_dof[NSTEP][NBLK + 4];
   // ---- actuators (lane = actuator)
@@ -370,6 +378,56 @@ inline BallHost build_ball_model(const Blob &b) {
     M.e_fmask[t][best] = e.fmask;
     M.e_rowstep[t][best] = (unsigned char)e.rowstep;
     M.e_colstep[t][best] = (unsigned char)e.colstep;
+  }
+  // ---- schedules
+  {
+    auto anc_off = [&](int k, int i) { return (int)__builtin_popcount(amask[k] & ~((2u << li[i]) - 1u)); };
+    int slot = 0;
+    for (int s = 0; s < NSTEP; s++) {  // factor: pivots of step s, every (i, j) with i a proper ancestor of the pivot
+      int fill = 0;
+      for (const Ent &e : ents) {
+        if (!((e.fmask >> s) & 1u)) continue;
+        int bb = blk[e.i], k = blk_start[bb + 1] - 1 - s;
+        if (fill == 0 && slot >= NFS) throw std::runtime_error("ball model: factor schedule too long");
+        M.fac_a[slot][fill] = (unsigned)e.adr | ((unsigned)madr[k] << 10) | ((unsigned)(madr[k] + anc_off(k, e.i)) << 20) | 0x80000000u;
+        M.fac_b[slot][fill] = (unsigned)(madr[k] + anc_off(k, e.j));
+        if (++fill == NL) { fill = 0; slot++; }
+      }
+      if (fill) slot++;
+    }
+    M.nfs = slot;
+    slot = 0;
+    for (int s = 0; s < NSTEP; s++) {  // pass 1: rows leaf -> root
+      int fill = 0;
+      for (const Ent &e : ents) {
+        if (e.i == e.j || e.rowstep != s) continue;
+        if (fill == 0 && slot >= NPS) throw std::runtime_error("ball model: solve schedule too long");
+        M.p1[slot][fill] = (unsigned)e.adr | ((unsigned)e.i << 10) | ((unsigned)e.j << 17) | 0x80000000u;
+        if (++fill == NL) { fill = 0; slot++; }
+      }
+      if (fill) slot++;
+    }
+    M.np1 = slot;
+    slot = 0;
+    for (int r = 0; r < NSTEP; r++) {  // pass 2: columns root -> leaf
+      int fill = 0;
+      for (const Ent &e : ents) {
+        if (e.i == e.j || e.colstep != r) continue;
+        if (fill == 0 && slot >= NPS) throw std::runtime_error("ball model: solve schedule too long");
+        M.p2[slot][fill] = (unsigned)e.adr | ((unsigned)e.i << 10) | ((unsigned)e.j << 17) | 0x80000000u;
+        if (++fill == NL) { fill = 0; slot++; }
+      }
+      if (fill) slot++;
+    }
+    M.np2 = slot;
+    int k = 0;
+    for (const Ent &e : ents) {
+      int t = k / NL, l = k % NL;
+      M.ent_a[t][l] = (unsigned)e.i | ((unsigned)e.j << 8) | ((unsigned)e.adr << 16) | 0x80000000u;
+      M.ent_b[t][l] = (unsigned)blk[e.i] | ((unsigned)li[e.i] << 4) | ((unsigned)li[e.j] << 8);
+      k++;
+    }
+    if ((int)ents.size() > ECAP * NL) throw std::runtime_error("ball model: too many M entries");
   }
   // ---- chains (fly dofs from the chain root to each link's last dof), capsules, sensors
   for (int l = 0; l < NL; l++) {
