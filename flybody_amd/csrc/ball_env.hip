@@ -35,13 +35,22 @@ enum { BF_NO_FLUID = 1, BF_NO_LIMIT = 2, BF_NO_DAMPER = 4, BF_NO_SPRING = 8, BF_
 // launch and keeps ~150 of them alive across the substep loop; an opaque copy forces the (cheap) address math to stay local.
 __device__ __forceinline__ unsigned opq(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int opq(int x) { asm volatile("" : "+v"(x)); return x; }
+#ifdef FFB_STAMPS
+__device__ unsigned long long g_bstamps[24];
+#define BSTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c.st_acc[k] += t_ - c.st_t0; c.st_t0 = t_; } while (0)
+#else
+#define BSTAMP(k) do { } while (0)
+#endif
 constexpr int kMaxNewton = 12;
-constexpr int kLsIter = 14;
+constexpr float kNewtonTol2 = 1e-10f;  // stop when |grad| <= 1e-5 |force scale|
+constexpr int kLsIter = 10;
+constexpr float kLsTol = 1e-3f;  // |phi'(alpha)| <= tol |phi'(0)|: an inexact line search, the Newton loop converges the rest
 
 struct alignas(16) BState {
   float q[NDP], v[NDP], act[64];
   float ballq[4], ballw[4];
-  int step_counter, needs_reset, overflow, iters, ncon, pad[3];
+  float qacc_ws[NDP], ballacc_ws[4];  // previous constraint-solver solution (mj: qacc_warmstart)
+  int step_counter, needs_reset, overflow, iters, ncon, have_ws, pad[2];
 };
 
 struct BTaskDev {
@@ -62,7 +71,7 @@ struct alignas(16) BTile {
   float frc[64];
   unsigned piv[NSTEP][16];  // pivot table of the block factorisation (copied from the model once per launch)
   int c_link[NC], c_blk[NC], c_excl[NC], c_nch[NC], c_adh[NC];
-  unsigned c_amask[NC];
+  unsigned c_amask[NC], c_bmask[16];  // c_bmask[b]: contacts whose chain lies in block b
   unsigned char c_chain[NC][16];
   float c_par[NC][8];  // K, B, invweight, friction, includemargin
   float c_pos[NC][3], c_frame[NC][9], c_dist[NC];
@@ -90,6 +99,12 @@ struct Ctx {
   Q4 bq;
   V3 bw, btau;
   int nc;
+  float aws[3];           // warm start of the constraint solver: last substep's solution
+  V3 abws;
+  int have_ws;
+#ifdef FFB_STAMPS
+  unsigned long long st_t0, st_acc[24];
+#endif
 };
 
 __device__ __forceinline__ bool slot_on(const Ctx &c, int s) { return c.sdof[s] >= 0; }
@@ -131,14 +146,14 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
     if (slot + 1 < nfs) { na = M.fac_a[slot + 1][lane]; nb = M.fac_b[slot + 1][lane]; }
     if (a >> 31) {
       const float lkk = dst[(a >> 10) & 0x3ffu], lki = dst[(a >> 20) & 0x3ffu], lkj = dst[b & 0x3ffu];
-      dst[a & 0x3ffu] -= lki * lkj / lkk;
+      dst[a & 0x3ffu] -= lki * lkj * frcp(lkk);
     }
     DM_SYNC();
   }
 #pragma unroll 2
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
-    if ((ea >> 31) && (ea & 0xffu) == ((ea >> 8) & 0xffu)) dinv[ea & 0xffu] = 1.f / dst[(ea >> 16) & 0x3ffu];
+    if ((ea >> 31) && (ea & 0xffu) == ((ea >> 8) & 0xffu)) dinv[ea & 0xffu] = frcp(dst[(ea >> 16) & 0x3ffu]);
   }
   DM_SYNC();
 #pragma unroll 2
@@ -258,6 +273,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     }
     DM_SYNC();
   }
+  BSTAMP(0);  // kinematics sweep
   const M3 xmat = q2m(c.xq);
   c.xip = c.xp + mv(xmat, V3{M.l_ipos[0][lane], M.l_ipos[1][lane], M.l_ipos[2][lane]});
   const M3 ximat = q2m(qmul(c.xq, Q4{M.l_iquat[0][lane], M.l_iquat[1][lane], M.l_iquat[2][lane], M.l_iquat[3][lane]}));
@@ -286,6 +302,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     }
     DM_SYNC();
   }
+  BSTAMP(1);  // velocity sweep
   // ---- body forces: rigid-body bias (mj_rne) minus inertia-box drag (mj_inertiaBoxFluidModel), about c0
   S6 ftot;
   {
@@ -315,6 +332,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     }
     DM_SYNC();
   }
+  BSTAMP(2);  // body forces + subtree sweep
   // ---- smooth joint forces without actuation: springs, dampers, -(bias - drag)
 #pragma unroll
   for (int s = 0; s < 3; s++) {
@@ -365,7 +383,9 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     }
   }
   DM_SYNC();
+  BSTAMP(3);  // joint forces + inertia assembly
   factor(c, T.Mq, false, T.Lm, T.dinv_m);
+  BSTAMP(4);  // factor M
   // ---- mj: mj_collision, ball (geom1, sphere) against this link's capsule: mjc_SphereCapsule
   bool hit = false;
   float dist = 0.f, margin = 0.f, gap = 0.f;
@@ -408,17 +428,27 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     fr[0] = nrm.x; fr[1] = nrm.y; fr[2] = nrm.z; fr[3] = t1.x; fr[4] = t1.y; fr[5] = t1.z; fr[6] = t2.x; fr[7] = t2.y; fr[8] = t2.z;
   }
   DM_SYNC();
+  if (lane < 16) {
+    unsigned bm = 0u;
+    for (int k = 0; k < c.nc; k++) if (T.c_blk[k] == lane) bm |= 1u << k;
+    T.c_bmask[lane] = bm;
+  }
+  DM_SYNC();
+  BSTAMP(5);  // collision
 }
 
 // sum over the contacts whose chain contains fly dof (blk, li) of  sum_r J[c][r][p] * w[c][r]
 __device__ __forceinline__ float contact_gather(const Ctx &c, unsigned sbl, const float (*w)[3]) {
   const BTile &T = *c.T;
-  const int blk = (int)(sbl & 0xffu);
   const unsigned li = sbl >> 8;
+  unsigned bm = T.c_bmask[sbl & 0xffu];
   float acc = 0.f;
-  for (int k = 0; k < c.nc; k++) {
-    if (T.c_blk[k] == blk && ((T.c_amask[k] >> li) & 1u)) {
-      const int p = __popc(T.c_amask[k] & ((1u << li) - 1u));
+  while (bm) {
+    const int k = __ffs(bm) - 1;
+    bm &= bm - 1u;
+    const unsigned am = T.c_amask[k];
+    if ((am >> li) & 1u) {
+      const int p = __popc(am & ((1u << li) - 1u));
       acc += T.c_J[k][0][p] * w[k][0] + T.c_J[k][1][p] * w[k][1] + T.c_J[k][2][p] * w[k][2];
     }
   }
@@ -472,18 +502,6 @@ __device__ __forceinline__ bool qcqp2(float &x0, float &x1, float A00, float A01
   }
   x0 = v0 * d; x1 = v1 * d;
   return active;
-}
-
-// contact-row residual jar = J a - aref for the contact owned by `lane` (a of the fly dofs staged in X4.x)
-__device__ __forceinline__ void contact_jar(const BTile &T, int k, V3 ab, float *jar) {
-  const int nch = T.c_nch[k];
-  jar[0] = -T.c_aref[k][0]; jar[1] = -T.c_aref[k][1]; jar[2] = -T.c_aref[k][2];
-  for (int p = 0; p < nch; p++) {
-    const float av = T.X4[T.c_chain[k][p]].x;
-    jar[0] += T.c_J[k][0][p] * av; jar[1] += T.c_J[k][1][p] * av; jar[2] += T.c_J[k][2][p] * av;
-  }
-#pragma unroll
-  for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[k][r][0] * ab.x + T.c_Jb[k][r][1] * ab.y + T.c_Jb[k][r][2] * ab.z;
 }
 
 // ------------------------------------------------------------------------------------------------ stage 2
@@ -544,28 +562,34 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
   }
   DM_SYNC();
-  // per-contact parameters (lane = contact) and the adhesion pull (mj: mj_transmission mjTRN_BODY: -force along the normal row)
-  if (lane < nc) {
-    const int nch = T.c_nch[lane];
-    float vel[3] = {0.f, 0.f, 0.f};
-    for (int p = 0; p < nch; p++) {
-      const float vv = T.V[T.c_chain[lane][p]];
-      vel[0] += T.c_J[lane][0][p] * vv; vel[1] += T.c_J[lane][1][p] * vv; vel[2] += T.c_J[lane][2][p] * vv;
-    }
+  // per-contact parameters and the adhesion pull (mj: mj_transmission mjTRN_BODY: -force along the normal row).
+  // Row-parallel: a row of 16 lanes handles one contact, lane p of the row the p-th dof of its chain.
+  for (int base = 0; base < nc; base += 4) {
+    const int k = base + (lane >> 4), p = lane & 15;
+    const bool on = k < nc;
+    const bool pv = on && p < T.c_nch[k];
+    const float vv = pv ? T.V[T.c_chain[k][p]] : 0.f;
+    float vel[3];
 #pragma unroll
-    for (int r = 0; r < 3; r++) vel[r] += T.c_Jb[lane][r][0] * c.bw.x + T.c_Jb[lane][r][1] * c.bw.y + T.c_Jb[lane][r][2] * c.bw.z;
-    const float K = T.c_par[lane][0], B = T.c_par[lane][1], invw = T.c_par[lane][2], incl = T.c_par[lane][4], dist = T.c_dist[lane];
-    const float imp = impedance(M.c_solimp, fabsf(dist - incl));
-    const float R0 = fmaxf(1e-15f, (1.f - imp) * invw / imp);
-    T.c_D[lane] = T.c_excl[lane] ? 0.f : 1.f / R0;
-    T.c_mu[lane] = T.c_par[lane][3];
-    T.c_aref[lane][0] = -B * vel[0] - K * imp * (dist - incl);
-    T.c_aref[lane][1] = -B * vel[1];
-    T.c_aref[lane][2] = -B * vel[2];
-    const int adh = T.c_adh[lane];
-    T.c_w[lane][0] = adh >= 0 ? -T.frc[adh] : 0.f; T.c_w[lane][1] = 0.f; T.c_w[lane][2] = 0.f;
+    for (int r = 0; r < 3; r++) {
+      vel[r] = row_sum(pv ? T.c_J[k][r][p] * vv : 0.f);
+      if (on) vel[r] += T.c_Jb[k][r][0] * c.bw.x + T.c_Jb[k][r][1] * c.bw.y + T.c_Jb[k][r][2] * c.bw.z;
+    }
+    if (on && p == 0) {
+      const float K = T.c_par[k][0], B = T.c_par[k][1], invw = T.c_par[k][2], incl = T.c_par[k][4], dist = T.c_dist[k];
+      const float imp = impedance(M.c_solimp, fabsf(dist - incl));
+      const float R0 = fmaxf(1e-15f, (1.f - imp) * invw / imp);
+      T.c_D[k] = T.c_excl[k] ? 0.f : 1.f / R0;
+      T.c_mu[k] = T.c_par[k][3];
+      T.c_aref[k][0] = -B * vel[0] - K * imp * (dist - incl);
+      T.c_aref[k][1] = -B * vel[1];
+      T.c_aref[k][2] = -B * vel[2];
+      const int adh = T.c_adh[k];
+      T.c_w[k][0] = adh >= 0 ? -T.frc[adh] : 0.f; T.c_w[k][1] = 0.f; T.c_w[k][2] = 0.f;
+    }
   }
   DM_SYNC();
+  BSTAMP(6);  // actuation + contact rows
   // ---- smooth forces and accelerations (mj: mj_fwdAcceleration)
   float qs[3], am[3];
 #pragma unroll
@@ -591,6 +615,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   for (int s = 0; s < 3; s++) am[s] = slot_on(c, s) ? T.X4[opq(c.sdof[s])].x : 0.f;
   const float Ib = M.b_I;
   const V3 amb = (1.f / Ib) * qsb;
+  BSTAMP(7);  // smooth solve
   // ---- joint-limit rows (mj: mj_instantiateLimit, margin 0): sign, D, aref per slot
   float lsgn[3], lD[3], laref[3];
 #pragma unroll
@@ -613,6 +638,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 #pragma unroll
   for (int s = 0; s < 3; s++) { a[s] = am[s]; Ma[s] = qs[s]; }
   V3 ab = amb;
+  const bool warm = c.have_ws != 0;
   int any_lim = 0;
 #pragma unroll
   for (int s = 0; s < 3; s++) any_lim |= (lsgn[s] != 0.f);
@@ -622,37 +648,64 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   int iters = 0;
   float lf[3] = {0.f, 0.f, 0.f};
   if (constrained) {
+    if (warm) {  // mj: qacc_warmstart.  M a of the starting point by one pass over M's entries (LDS float adds)
+#pragma unroll
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) { a[s] = c.aws[s]; T.X4[opq(c.sdof[s])].x = a[s]; T.dadd[opq(c.sdof[s])] = 0.f; }
+      ab = c.abws;
+      DM_SYNC();
+#pragma unroll 2
+      for (int t = 0; t < ECAP; t++) {
+        const unsigned ea = M.ent_a[t][lane];
+        if (ea >> 31) {
+          const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu;
+          const float mv_ = T.Mq[(ea >> 16) & 0x3ffu];
+          atomicAdd(&T.dadd[i], mv_ * T.X4[j].x);
+          if (i != j) atomicAdd(&T.dadd[j], mv_ * T.X4[i].x);
+        }
+      }
+      DM_SYNC();
+#pragma unroll
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) Ma[s] = T.dadd[opq(c.sdof[s])];
+      DM_SYNC();
+    }
 #pragma unroll 1
     for (int it = 0; it < kMaxNewton; it++) {
       // contact residuals, forces, local Hessians (lane = contact)
 #pragma unroll
       for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = a[s];
       DM_SYNC();
-      if (lane < nc) {
-        const int nch = T.c_nch[lane];
-        float jar[3];
-        contact_jar(T, lane, ab, jar);
+      for (int base = 0; base < nc; base += 4) {
+        const int k = base + (lane >> 4), p = lane & 15;
+        const bool on = k < nc;
+        const bool pv = on && p < T.c_nch[k];
+        const float av = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
+        const float x0 = pv ? T.c_J[k][0][p] : 0.f, x1 = pv ? T.c_J[k][1][p] : 0.f, x2 = pv ? T.c_J[k][2][p] : 0.f;
+        float jar[3] = {row_sum(x0 * av), row_sum(x1 * av), row_sum(x2 * av)};
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, Hc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (!T.c_excl[lane]) cone_force(T.c_D[lane], T.c_mu[lane], jar[0], jar[1], jar[2], f0, f1, f2, Hc);
-        T.c_jar[lane][0] = jar[0]; T.c_jar[lane][1] = jar[1]; T.c_jar[lane][2] = jar[2];
-        T.c_f[lane][0] = f0; T.c_f[lane][1] = f1; T.c_f[lane][2] = f2;
-        for (int k = 0; k < 9; k++) T.c_Hc[lane][k] = Hc[k];
-        // JB = Hc J over the chain and the ball columns
-        for (int p = 0; p < nch; p++) {
-          const float x0 = T.c_J[lane][0][p], x1 = T.c_J[lane][1][p], x2 = T.c_J[lane][2][p];
-          T.c_JB[lane][0][p] = Hc[0] * x0 + Hc[1] * x1 + Hc[2] * x2;
-          T.c_JB[lane][1][p] = Hc[3] * x0 + Hc[4] * x1 + Hc[5] * x2;
-          T.c_JB[lane][2][p] = Hc[6] * x0 + Hc[7] * x1 + Hc[8] * x2;
-        }
+        if (on) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const float x0 = T.c_Jb[lane][0][k], x1 = T.c_Jb[lane][1][k], x2 = T.c_Jb[lane][2][k];
-          T.c_JBb[lane][0][k] = Hc[0] * x0 + Hc[1] * x1 + Hc[2] * x2;
-          T.c_JBb[lane][1][k] = Hc[3] * x0 + Hc[4] * x1 + Hc[5] * x2;
-          T.c_JBb[lane][2][k] = Hc[6] * x0 + Hc[7] * x1 + Hc[8] * x2;
+          for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[k][r][0] * ab.x + T.c_Jb[k][r][1] * ab.y + T.c_Jb[k][r][2] * ab.z - T.c_aref[k][r];
+          if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], jar[0], jar[1], jar[2], f0, f1, f2, Hc);
+          if (p == 0) {
+            T.c_jar[k][0] = jar[0]; T.c_jar[k][1] = jar[1]; T.c_jar[k][2] = jar[2];
+            T.c_f[k][0] = f0; T.c_f[k][1] = f1; T.c_f[k][2] = f2;
+            for (int q2 = 0; q2 < 9; q2++) T.c_Hc[k][q2] = Hc[q2];
+          }
+          if (pv) {  // JB = Hc J, this lane's chain column
+            T.c_JB[k][0][p] = Hc[0] * x0 + Hc[1] * x1 + Hc[2] * x2;
+            T.c_JB[k][1][p] = Hc[3] * x0 + Hc[4] * x1 + Hc[5] * x2;
+            T.c_JB[k][2][p] = Hc[6] * x0 + Hc[7] * x1 + Hc[8] * x2;
+          }
+          if (p < 3) {  // and the ball columns
+            const float y0 = T.c_Jb[k][0][p], y1 = T.c_Jb[k][1][p], y2 = T.c_Jb[k][2][p];
+            T.c_JBb[k][0][p] = Hc[0] * y0 + Hc[1] * y1 + Hc[2] * y2;
+            T.c_JBb[k][1][p] = Hc[3] * y0 + Hc[4] * y1 + Hc[5] * y2;
+            T.c_JBb[k][2][p] = Hc[6] * y0 + Hc[7] * y1 + Hc[8] * y2;
+          }
         }
       }
       DM_SYNC();
+      BSTAMP(8);  // newton: contact forces / local Hessians
       // gradient (fly slots + ball), Hessian diagonal additions, coupling columns
       float g[3], hadd[3], hfb[3][3];
       float gn2 = 0.f, fn2 = 0.f;
@@ -667,10 +720,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           }
           if (nc) {
             gg -= contact_gather(c, opq(c.sbl[s]), T.c_f);
-            const int blk = (int)(opq(c.sbl[s]) & 0xffu);
             const unsigned li = opq(c.sbl[s]) >> 8;
-            for (int k = 0; k < nc; k++) {
-              if (T.c_blk[k] == blk && ((T.c_amask[k] >> li) & 1u)) {
+            unsigned bm = T.c_bmask[opq(c.sbl[s]) & 0xffu];
+            while (bm) {
+              const int k = __ffs(bm) - 1;
+              bm &= bm - 1u;
+              if ((T.c_amask[k] >> li) & 1u) {
                 const int p = __popc(T.c_amask[k] & ((1u << li) - 1u));
                 const float x0 = T.c_J[k][0][p], x1 = T.c_J[k][1][p], x2 = T.c_J[k][2][p];
 #pragma unroll
@@ -701,8 +756,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       }
       gn2 = wave_sum(gn2) + dot(gb, gb);
       fn2 = wave_sum(fn2) + dot(qsb, qsb);
-      if (it > 0 && gn2 <= 1e-11f * fn2 + 1e-30f) break;
+      if ((it > 0 || warm) && gn2 <= kNewtonTol2 * fn2 + 1e-30f) break;
       iters++;
+      BSTAMP(9);  // newton: gradient
       // H_ff = M + diag(limit D) + sum_c J_f' Hc J_f  (same sparsity as M: a contact row only spans one chain)
       DM_SYNC();
 #pragma unroll 1
@@ -712,9 +768,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu, adr = (ea >> 16) & 0x3ffu, blk = eb & 0xfu, lii = (eb >> 4) & 0xfu, lij = (eb >> 8) & 0xfu;
           float hv = T.Mq[adr];
           if (i == j) hv += T.dadd[i];
-          for (int k = 0; k < nc; k++) {
-            if (T.c_blk[k] == (int)blk && ((T.c_amask[k] >> lii) & 1u)) {
-              const unsigned am_ = T.c_amask[k];
+          unsigned bm = T.c_bmask[blk];
+          while (bm) {
+            const int k = __ffs(bm) - 1;
+            bm &= bm - 1u;
+            const unsigned am_ = T.c_amask[k];
+            if ((am_ >> lii) & 1u) {
               const int pi = __popc(am_ & ((1u << lii) - 1u)), pj = __popc(am_ & ((1u << lij) - 1u));
               hv += T.c_J[k][0][pi] * T.c_JB[k][0][pj] + T.c_J[k][1][pi] * T.c_JB[k][1][pj] + T.c_J[k][2][pi] * T.c_JB[k][2][pj];
             }
@@ -723,12 +782,15 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         }
       }
       DM_SYNC();
+      BSTAMP(10);  // newton: H assembly
       factor(c, T.Lh, false, T.Lh, T.dinv_h);
+      BSTAMP(11);  // newton: factor
       // [ -g_f | H_fb ] through H_ff^-1, then the 3x3 Schur complement on the ball
 #pragma unroll
       for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(-g[s], hfb[s][0], hfb[s][1], hfb[s][2]);
       DM_SYNC();
       solve4(c, T.Lh, T.dinv_h);
+      BSTAMP(12);  // newton: solve
       float4 xs[3];
       float sc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // S reductions: xx xy xz yy yz zz, rhs x y z
 #pragma unroll
@@ -760,20 +822,23 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 #pragma unroll
       for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = dd[s];
       DM_SYNC();
-      if (lane < nc) {
-        const int nch = T.c_nch[lane];
-        float jd[3] = {0.f, 0.f, 0.f};
-        for (int p = 0; p < nch; p++) {
-          const float dv = T.X4[T.c_chain[lane][p]].x;
-          jd[0] += T.c_J[lane][0][p] * dv; jd[1] += T.c_J[lane][1][p] * dv; jd[2] += T.c_J[lane][2][p] * dv;
-        }
+      for (int base = 0; base < nc; base += 4) {
+        const int k = base + (lane >> 4), p = lane & 15;
+        const bool on = k < nc;
+        const bool pv = on && p < T.c_nch[k];
+        const float dv = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
+        float jd[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) jd[r] += T.c_Jb[lane][r][0] * db.x + T.c_Jb[lane][r][1] * db.y + T.c_Jb[lane][r][2] * db.z;
-        const float *Hc = T.c_Hc[lane];
-        T.c_jd[lane][0] = jd[0]; T.c_jd[lane][1] = jd[1]; T.c_jd[lane][2] = jd[2];
-        T.c_w[lane][0] = Hc[0] * jd[0] + Hc[1] * jd[1] + Hc[2] * jd[2];
-        T.c_w[lane][1] = Hc[3] * jd[0] + Hc[4] * jd[1] + Hc[5] * jd[2];
-        T.c_w[lane][2] = Hc[6] * jd[0] + Hc[7] * jd[1] + Hc[8] * jd[2];
+        for (int r = 0; r < 3; r++) jd[r] = row_sum(pv ? T.c_J[k][r][p] * dv : 0.f);
+        if (on && p == 0) {
+#pragma unroll
+          for (int r = 0; r < 3; r++) jd[r] += T.c_Jb[k][r][0] * db.x + T.c_Jb[k][r][1] * db.y + T.c_Jb[k][r][2] * db.z;
+          const float *Hc = T.c_Hc[k];
+          T.c_jd[k][0] = jd[0]; T.c_jd[k][1] = jd[1]; T.c_jd[k][2] = jd[2];
+          T.c_w[k][0] = Hc[0] * jd[0] + Hc[1] * jd[1] + Hc[2] * jd[2];
+          T.c_w[k][1] = Hc[3] * jd[0] + Hc[4] * jd[1] + Hc[5] * jd[2];
+          T.c_w[k][2] = Hc[6] * jd[0] + Hc[7] * jd[1] + Hc[8] * jd[2];
+        }
       }
       DM_SYNC();
       float Md[3], c0s = 0.f, c1s = 0.f;
@@ -789,6 +854,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       }
       c0s = wave_sum(c0s) + dot(Ib * ab - qsb, db);
       c1s = wave_sum(c1s) + Ib * dot(db, db);
+      BSTAMP(13);  // newton: Schur, jd, Md
       // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(jar + alpha jd) jd
       auto dphi = [&](float al) {
         float acc = 0.f;
@@ -813,18 +879,18 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         if (!(d0 < 0.f)) break;  // not a descent direction any more: converged to rounding
         float lo = 0.f, hi = 1.f, dlo = d0, dhi = dphi(1.f);
         int guard = 0;
-        while (dhi < 0.f && guard++ < 8) { lo = hi; dlo = dhi; hi *= 2.f; dhi = dphi(hi); }
-        if (dhi < 0.f) alpha = hi;
+        while (dhi < 0.f && fabsf(dhi) > kLsTol * fabsf(d0) && guard++ < 8) { lo = hi; dlo = dhi; hi *= 2.f; dhi = dphi(hi); }
+        if (dhi < 0.f || fabsf(dhi) <= kLsTol * fabsf(d0)) alpha = hi;  // full (or doubled) Newton step: |phi'| already small
         else {
 #pragma unroll 1
           for (int ls = 0; ls < kLsIter; ls++) {
-            if (fabsf(dhi) <= 1e-6f * fabsf(d0)) { lo = hi; dlo = dhi; break; }
+            if (fabsf(dhi) <= kLsTol * fabsf(d0)) { lo = hi; dlo = dhi; break; }
             // regula falsi step safeguarded by bisection
             float mid = lo - dlo * (hi - lo) / (dhi - dlo);
             if (!(mid > lo + 0.05f * (hi - lo)) || !(mid < hi - 0.05f * (hi - lo))) mid = 0.5f * (lo + hi);
             const float dm_ = dphi(mid);
             if (dm_ < 0.f) { lo = mid; dlo = dm_; } else { hi = mid; dhi = dm_; }
-            if (fabsf(dm_) <= 1e-6f * fabsf(d0) || hi - lo <= 1e-6f * hi) break;
+            if (fabsf(dm_) <= kLsTol * fabsf(d0) || hi - lo <= 1e-6f * hi) break;
           }
           alpha = (dhi - dlo) != 0.f ? lo - dlo * (hi - lo) / (dhi - dlo) : hi;
           if (!(alpha >= lo) || !(alpha <= hi)) alpha = 0.5f * (lo + hi);
@@ -833,17 +899,27 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 #pragma unroll
       for (int s = 0; s < 3; s++) { a[s] += alpha * dd[s]; Ma[s] += alpha * Md[s]; }
       ab = ab + alpha * db;
+      BSTAMP(14);  // newton: line search
     }
     // final forces at the solution
 #pragma unroll
     for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = a[s];
     DM_SYNC();
-    if (lane < nc) {
+    for (int base = 0; base < nc; base += 4) {
+      const int k = base + (lane >> 4), p = lane & 15;
+      const bool on = k < nc;
+      const bool pv = on && p < T.c_nch[k];
+      const float av = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
       float jar[3];
-      contact_jar(T, lane, ab, jar);
-      float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-      if (!T.c_excl[lane]) cone_force(T.c_D[lane], T.c_mu[lane], jar[0], jar[1], jar[2], f0, f1, f2, nullptr);
-      T.c_f[lane][0] = f0; T.c_f[lane][1] = f1; T.c_f[lane][2] = f2;
+#pragma unroll
+      for (int r = 0; r < 3; r++) jar[r] = row_sum(pv ? T.c_J[k][r][p] * av : 0.f);
+      if (on && p == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[k][r][0] * ab.x + T.c_Jb[k][r][1] * ab.y + T.c_Jb[k][r][2] * ab.z - T.c_aref[k][r];
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], jar[0], jar[1], jar[2], f0, f1, f2, nullptr);
+        T.c_f[k][0] = f0; T.c_f[k][1] = f1; T.c_f[k][2] = f2;
+      }
     }
 #pragma unroll
     for (int s = 0; s < 3; s++) {
@@ -856,51 +932,40 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     DM_SYNC();
   }
   iters_out += iters;
+  BSTAMP(15);  // newton: final forces
   // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
   //      unregularised A = J M^-1 J'; everything else (normal and limit forces) enters through w0 = M^-1 J' f_other
   bool did_noslip = false;
   if (nact > 0 && M.noslip_iterations > 0 && !(c.flags & BF_NO_NOSLIP)) {
     did_noslip = true;
     const int nr = 2 * nc;
-    // w0
+    // right-hand sides through M^-1 four at a time: column 0 of the first batch is J' f_other (-> w0), the rest are the
+    // tangential rows J_t' (-> the columns of A_tt, written straight into the idle link-exchange buffer)
     for (int k = lane; k < nc; k += 64) { T.c_w[k][0] = T.c_f[k][0]; T.c_w[k][1] = 0.f; T.c_w[k][2] = 0.f; }
     DM_SYNC();
+    float w0rhs[3];
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-      if (slot_on(c, s)) {
-        float f = lsgn[s] * lf[s] + contact_gather(c, opq(c.sbl[s]), T.c_w);
-        T.X4[opq(c.sdof[s])] = make_float4(f, 0.f, 0.f, 0.f);
-      }
+      w0rhs[s] = 0.f;
+      if (slot_on(c, s)) { w0rhs[s] = lsgn[s] * lf[s] + contact_gather(c, opq(c.sbl[s]), T.c_w); T.dadd[opq(c.sdof[s])] = am[s]; }
     }
     V3 w0b = {0.f, 0.f, 0.f};
     for (int k = 0; k < nc; k++) {
       w0b.x += T.c_Jb[k][0][0] * T.c_f[k][0]; w0b.y += T.c_Jb[k][0][1] * T.c_f[k][0]; w0b.z += T.c_Jb[k][0][2] * T.c_f[k][0];
     }
     w0b = (1.f / Ib) * w0b;
-    DM_SYNC();
-    solve4(c, T.Lm, T.dinv_m);
-    // b' = J_t (a_smooth + w0) - aref_t  (lane = tangential row)
-#pragma unroll
-    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x += am[s];
-    DM_SYNC();
     float brow = 0.f;
-    if (lane < nr) {
-      const int k = lane >> 1, r = 1 + (lane & 1), nch = T.c_nch[k];
-      float sacc = -T.c_aref[k][r];
-      for (int p = 0; p < nch; p++) sacc += T.c_J[k][r][p] * T.X4[T.c_chain[k][p]].x;
-      const V3 ub = amb + w0b;
-      sacc += T.c_Jb[k][r][0] * ub.x + T.c_Jb[k][r][1] * ub.y + T.c_Jb[k][r][2] * ub.z;
-      brow = sacc;
-    }
-    DM_SYNC();
-    // A_tt, four columns per solve, written straight into the (idle) link-exchange buffer
 #pragma unroll 1
-    for (int base = 0; base < nr; base += 4) {
+    for (int base = -1; base < nr; base += 4) {  // columns base .. base + 3 (column -1 = w0)
       for (int f = lane; f < ND; f += 64) T.X4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
       DM_SYNC();
+      if (base < 0) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = w0rhs[s];
+      }
       for (int item = lane; item < 4 * NCH; item += 64) {
         const int col = item / NCH, p = item - col * NCH, row = base + col;
-        if (row < nr) {
+        if (row >= 0 && row < nr) {
           const int k = row >> 1, r = 1 + (row & 1);
           if (p < T.c_nch[k]) (&T.X4[T.c_chain[k][p]].x)[col] = T.c_J[k][r][p];
         }
@@ -910,15 +975,22 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       if (lane < nr) {
         const int k = lane >> 1, r = 1 + (lane & 1), nch = T.c_nch[k];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float accs = 0.f;
         for (int p = 0; p < nch; p++) {
           const float jv = T.c_J[k][r][p];
-          const float4 y = T.X4[T.c_chain[k][p]];
+          const int f = T.c_chain[k][p];
+          const float4 y = T.X4[f];
           acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
+          if (base < 0) accs += jv * T.dadd[f];
+        }
+        if (base < 0) {  // b' = J_t (a_smooth + w0) - aref_t
+          const V3 ub = amb + w0b;
+          brow = accs + acc.x - T.c_aref[k][r] + T.c_Jb[k][r][0] * ub.x + T.c_Jb[k][r][1] * ub.y + T.c_Jb[k][r][2] * ub.z;
         }
 #pragma unroll
         for (int col = 0; col < 4; col++) {
           const int row = base + col;
-          if (row < nr) {
+          if (row >= 0 && row < nr) {
             const int k2 = row >> 1, r2 = 1 + (row & 1);
             const float ball = (T.c_Jb[k][r][0] * T.c_Jb[k2][r2][0] + T.c_Jb[k][r][1] * T.c_Jb[k2][r2][1] + T.c_Jb[k][r][2] * T.c_Jb[k2][r2][2]) / Ib;
             T.ns.A[lane][row] = (col == 0 ? acc.x : (col == 1 ? acc.y : (col == 2 ? acc.z : acc.w))) + ball;
@@ -970,6 +1042,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     if (lane < nr) T.c_f[lane >> 1][1 + (lane & 1)] = T.ns.f[lane];
     DM_SYNC();
   }
+  BSTAMP(16);  // noslip
   // ---- constraint forces in joint space, final acceleration
   float qc[3];
 #pragma unroll
@@ -1002,7 +1075,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 #pragma unroll
     for (int s = 0; s < 3; s++) if (slot_on(c, s)) n2 += a[s] * a[s];
     *qacc_norm2 = wave_sum(n2) + dot(ab, ab);
+#pragma unroll
+    for (int s = 0; s < 3; s++) c.aws[s] = a[s];
+    c.abws = ab;
+    c.have_ws = 1;
   }
+  BSTAMP(17);  // constraint forces, final acceleration
   // ---- sensors (mj: mj_rnePostConstraint + mj_sensorAcc): touch = normal force on the claw, force = interaction
   //      force on the tarsus from its parent, in the tarsus site frame.  Only the linear part of the spatial force is
   //      needed: m (a_lin + alpha x r + w x (v_lin + w x r)) with r = CoM - origin.
@@ -1056,6 +1134,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     if (ti >= 0) T.sens[18 + ti] += touch;
     DM_SYNC();
   }
+  BSTAMP(18);  // sensors
   if (!integrate) return;  // mj_forward: state untouched
   // ---- Euler with implicit joint damping (mj: mj_Euler): (M + h B) qacc_e = qfrc_smooth + qfrc_constraint
   float damp[3];
@@ -1094,6 +1173,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       c.bq = qnormalize(qmul(qnormalize(c.bq), dq));
     }
   }
+  BSTAMP(19);  // Euler
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
@@ -1107,6 +1187,10 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   BState &S = states[env];
   Ctx c;
   c.M = Mp; c.T = &T; c.lane = lane; c.flags = K.flags;
+#ifdef FFB_STAMPS
+  c.st_t0 = __builtin_amdgcn_s_memtime();
+  for (int k = 0; k < 24; k++) c.st_acc[k] = 0;
+#endif
   c.lpack = M.l_pack[lane]; c.lkids = M.l_kids[lane]; c.xh = M.x_on[lane];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
@@ -1127,11 +1211,17 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     for (int s = 0; s < 3; s++)
       if (slot_on(c, s)) for (int w = 0; w < M.nwing; w++) if (M.wing_dof[w] == c.sdof[s]) c.q[s] = M.qspring[c.sdof[s]];
     c.bq = {1.f, 0.f, 0.f, 0.f}; c.bw = {0.f, 0.f, 0.f};
+    c.have_ws = 0; c.abws = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 3; s++) c.aws[s] = 0.f;
     step_counter = 0;
   } else {
 #pragma unroll
     for (int s = 0; s < 3; s++) { c.q[s] = slot_on(c, s) ? S.q[c.sdof[s]] : 0.f; c.v[s] = slot_on(c, s) ? S.v[c.sdof[s]] : 0.f; }
     c.bq = {S.ballq[0], S.ballq[1], S.ballq[2], S.ballq[3]}; c.bw = {S.ballw[0], S.ballw[1], S.ballw[2]};
+    c.have_ws = S.have_ws; c.abws = {S.ballacc_ws[0], S.ballacc_ws[1], S.ballacc_ws[2]};
+#pragma unroll
+    for (int s = 0; s < 3; s++) c.aws[s] = slot_on(c, s) ? S.qacc_ws[c.sdof[s]] : 0.f;
     act_reg = lane < NU ? S.act[lane] : 0.f;
     if (lane < NU) {
       if (phys_only) ctrl_reg = act[(size_t)env * NU + lane];
@@ -1168,13 +1258,18 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   c.flags = K.flags;
   // ---- store state
 #pragma unroll
-  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { S.q[c.sdof[s]] = c.q[s]; S.v[c.sdof[s]] = c.v[s]; }
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { S.q[c.sdof[s]] = c.q[s]; S.v[c.sdof[s]] = c.v[s]; S.qacc_ws[c.sdof[s]] = c.aws[s]; }
   if (lane < NU) S.act[lane] = do_reset ? 0.f : act_reg;
   if (lane == 0) {
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
     S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc;
+    S.have_ws = do_reset ? 0 : c.have_ws; S.ballacc_ws[0] = c.abws.x; S.ballacc_ws[1] = c.abws.y; S.ballacc_ws[2] = c.abws.z;
   }
+#ifdef FFB_STAMPS
+  BSTAMP(20);  // prologue + state store
+  if (lane == 0) for (int k = 0; k < 24; k++) atomicAdd(&g_bstamps[k], c.st_acc[k]);
+#endif
   if (phys_only) return;
   // ---- observation (ref: SURVEY App. A order): accelerometer 3 | actuator_activation 59 | appendages_pos 21 | ball_qvel 3 |
   //      force 18 | gyro 3 | joints_pos 85 | joints_vel 85 | touch 6 | velocimeter 3 | world_zaxis 3
@@ -1248,6 +1343,7 @@ __global__ void ball_set_state_kernel(BState *states, const double *qpos, const 
   BState &S = states[env];
   for (int k = t; k < 106; k += blockDim.x) { if (k < 4) S.ballq[k] = (float)qpos[(size_t)env * 106 + k]; else S.q[k - 4] = (float)qpos[(size_t)env * 106 + k]; }
   for (int k = t; k < 105; k += blockDim.x) { if (k < 3) S.ballw[k] = (float)qvel[(size_t)env * 105 + k]; else S.v[k - 3] = (float)qvel[(size_t)env * 105 + k]; }
+  if (t == 0) S.have_ws = 0;
 }
 __global__ void ball_act_kernel(BState *states, double *act, int batch, int set) {
   const int env = blockIdx.x, t = threadIdx.x;
@@ -1347,6 +1443,13 @@ void ball_get_task_state(BallEnv *e, int32_t *ints, double *reals, void *stream)
   hipLaunchKernelGGL(ball_task_state_kernel, dim3((e->batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->states, ints, reals, e->batch);
   HIPB_OK(hipGetLastError());
 }
+#ifdef FFB_STAMPS
+extern "C" int ffb_debug_read_stamps(unsigned long long *out24, int reset) {
+  if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_bstamps), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 float ball_time_steps(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   HIPB_OK(hipEventRecord(e->ev0, s));

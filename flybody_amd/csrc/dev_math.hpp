@@ -90,6 +90,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
 }
 
+// sum within each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ float row_sum(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  return v;
+}
+// 1/x: hardware reciprocal + one Newton step (full float32 accuracy without the IEEE division sequence)
+__device__ __forceinline__ float frcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return r * (2.f - x * r);
+}
+
 // One workgroup = one wavefront: LDS operations of a wave execute in issue order, so publishing a lane's LDS write to
 // the other lanes only needs the compiler not to reorder across this point.
 #define DM_SYNC()                                                \
