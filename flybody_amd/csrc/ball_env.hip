@@ -58,26 +58,27 @@ struct BTaskDev {
 };
 
 struct alignas(16) BTile {
-  float Q[NDP], V[NDP];
-  float4 X4[NDP];
+  union {
+    struct { float Q[NDP], V[NDP]; };  // joint state staged for the actuators / contact rows (start of stage 2) and the observation
+    float4 X4[NDP];                     // right-hand sides / solutions of the block solves (from the smooth solve on)
+  };
   float Mq[NMMAX], Lm[NMMAX], Lh[NMMAX];
   float dinv_m[NDP], dinv_h[NDP], dadd[NDP];
   float C[NDP][6];
   union {
     float F[NDP][6];    // crb * cdof during the inertia assembly
-    float lk[NL][16];   // link exchange of the level sweeps: pose (7) | velocity + acceleration (12) | crb + force (16)
+    float lk[NL][12];   // link exchange of the level sweeps: pose (7) | velocity + acceleration (12) | crb (10) | force (6)
     struct { float A[2 * NC][2 * NC + 1], b[2 * NC], f[2 * NC]; } ns;  // noslip: unregularised tangential block
   };
   float frc[64];
-  unsigned piv[NSTEP][16];  // pivot table of the block factorisation (copied from the model once per launch)
   int c_link[NC], c_blk[NC], c_excl[NC], c_nch[NC], c_adh[NC];
   unsigned c_amask[NC], c_bmask[16];  // c_bmask[b]: contacts whose chain lies in block b
   unsigned char c_chain[NC][16];
-  float c_par[NC][8];  // K, B, invweight, friction, includemargin
+  float c_par[NC][5];  // K, B, invweight, friction, includemargin
   float c_pos[NC][3], c_frame[NC][9], c_dist[NC];
-  float c_J[NC][3][NCH + 2], c_JB[NC][3][NCH + 2], c_Jb[NC][3][3], c_JBb[NC][3][3];
+  float c_J[NC][3][NCH], c_JB[NC][3][NCH], c_Jb[NC][3][3], c_JBb[NC][3][3];
   float c_D[NC], c_mu[NC], c_aref[NC][3], c_f[NC][3], c_Hc[NC][9], c_jar[NC][3], c_jd[NC][3], c_w[NC][3];
-  float sens[32];  // running sums of the buffered sensors: force 18, touch 6
+  float sens[24];  // running sums of the buffered sensors: force 18, touch 6
 };
 
 // ------------------------------------------------------------------------------------------------ per-lane context
@@ -111,8 +112,11 @@ __device__ __forceinline__ bool slot_on(const Ctx &c, int s) { return c.sdof[s] 
 __device__ __forceinline__ int l_parent(const Ctx &c) { return (int)(c.lpack & 0xffu) - 1; }
 __device__ __forceinline__ int l_depth(const Ctx &c) { return (int)((c.lpack >> 8) & 0xfu); }
 __device__ __forceinline__ int l_ndof(const Ctx &c) { return (int)((c.lpack >> 12) & 0x3u); }
-__device__ __forceinline__ const BallModel &model(const Ctx &c) {
-  const BallModel *m = c.M;
+// The tables are read through an address-space-1 pointer: a generic pointer makes every table read a FLAT load, which
+// counts against the LDS wait counter as well, so each LDS wait would also wait for the schedule prefetch.
+typedef const BallModel FFE_GLOBAL *ModelPtr;
+__device__ __forceinline__ const BallModel FFE_GLOBAL &model(const Ctx &c) {
+  ModelPtr m = (ModelPtr)c.M;
   asm volatile("" : "+s"(m));
   return *m;
 }
@@ -125,7 +129,7 @@ __device__ __forceinline__ const BallModel &model(const Ctx &c) {
 // LDS operations of a wave complete in issue order, which is all the ordering the steps need.
 __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, float *dst, float *dinv) {
   BTile &T = *c.T;
-  const BallModel &M = model(c);
+  const BallModel FFE_GLOBAL &M = model(c);
   const int lane = c.lane;
 #pragma unroll 2
   for (int t = 0; t < ECAP; t++) {
@@ -138,18 +142,31 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
     }
   }
   DM_SYNC();
+  // Schedule words are fetched one group of four slots ahead (tables are zero padded past nfs).  No fence inside the loop:
+  // a wavefront-scope release fence waits for ALL outstanding memory operations, i.e. it would stall on the prefetch;
+  // the LDS accesses of consecutive slots may alias, so the compiler keeps their order, and the hardware executes a
+  // wave's LDS operations in issue order.
   const int nfs = M.nfs;
-  unsigned na = M.fac_a[0][lane], nb = M.fac_b[0][lane];
+  unsigned wa[4], wb[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { wa[q] = M.fac_a[q][lane]; wb[q] = M.fac_b[q][lane]; }
 #pragma unroll 1
-  for (int slot = 0; slot < nfs; slot++) {
-    const unsigned a = na, b = nb;
-    if (slot + 1 < nfs) { na = M.fac_a[slot + 1][lane]; nb = M.fac_b[slot + 1][lane]; }
-    if (a >> 31) {
-      const float lkk = dst[(a >> 10) & 0x3ffu], lki = dst[(a >> 20) & 0x3ffu], lkj = dst[b & 0x3ffu];
-      dst[a & 0x3ffu] -= lki * lkj * frcp(lkk);
+  for (int base = 0; base < nfs; base += 4) {
+    unsigned ca[4], cb[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { ca[q] = wa[q]; cb[q] = wb[q]; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { wa[q] = M.fac_a[base + 4 + q][lane]; wb[q] = M.fac_b[base + 4 + q][lane]; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const unsigned a = ca[q], b = cb[q];
+      if (a >> 31) {
+        const float lkk = dst[(a >> 10) & 0x3ffu], lki = dst[(a >> 20) & 0x3ffu], lkj = dst[b & 0x3ffu];
+        dst[a & 0x3ffu] -= lki * lkj * frcp(lkk);
+      }
     }
-    DM_SYNC();
   }
+  DM_SYNC();
 #pragma unroll 2
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
@@ -168,25 +185,34 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
 // schedules p1 / p2 (slots of 64 independent updates in step order)
 __device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv) {
   BTile &T = *c.T;
-  const BallModel &M = model(c);
+  const BallModel FFE_GLOBAL &M = model(c);
   const int lane = c.lane;
   {
     const int n = M.np1;
-    unsigned nw = M.p1[0][lane];
+    unsigned wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wq[q] = M.p1[q][lane];
 #pragma unroll 1
-    for (int slot = 0; slot < n; slot++) {
-      const unsigned w = nw;
-      if (slot + 1 < n) nw = M.p1[slot + 1][lane];
-      if (w >> 31) {
-        const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
-        const float l = L[w & 0x3ffu];
-        const float4 xi = T.X4[i];
-        float4 xj = T.X4[j];
-        xj.x -= l * xi.x; xj.y -= l * xi.y; xj.z -= l * xi.z; xj.w -= l * xi.w;
-        T.X4[j] = xj;
+    for (int base = 0; base < n; base += 4) {
+      unsigned cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) cw[q] = wq[q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) wq[q] = M.p1[base + 4 + q][lane];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const unsigned w = cw[q];
+        if (w >> 31) {
+          const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
+          const float l = L[w & 0x3ffu];
+          const float4 xi = T.X4[i];
+          float4 xj = T.X4[j];
+          xj.x -= l * xi.x; xj.y -= l * xi.y; xj.z -= l * xi.z; xj.w -= l * xi.w;
+          T.X4[j] = xj;
+        }
       }
-      DM_SYNC();
     }
+    DM_SYNC();
   }
   for (int f = lane; f < ND; f += 64) {
     const float dv = dinv[f];
@@ -197,21 +223,30 @@ __device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv
   DM_SYNC();
   {
     const int n = M.np2;
-    unsigned nw = M.p2[0][lane];
+    unsigned wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wq[q] = M.p2[q][lane];
 #pragma unroll 1
-    for (int slot = 0; slot < n; slot++) {
-      const unsigned w = nw;
-      if (slot + 1 < n) nw = M.p2[slot + 1][lane];
-      if (w >> 31) {
-        const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
-        const float l = L[w & 0x3ffu];
-        const float4 xj = T.X4[j];
-        float4 xi = T.X4[i];
-        xi.x -= l * xj.x; xi.y -= l * xj.y; xi.z -= l * xj.z; xi.w -= l * xj.w;
-        T.X4[i] = xi;
+    for (int base = 0; base < n; base += 4) {
+      unsigned cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) cw[q] = wq[q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) wq[q] = M.p2[base + 4 + q][lane];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const unsigned w = cw[q];
+        if (w >> 31) {
+          const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
+          const float l = L[w & 0x3ffu];
+          const float4 xj = T.X4[j];
+          float4 xi = T.X4[i];
+          xi.x -= l * xj.x; xi.y -= l * xj.y; xi.z -= l * xj.z; xi.w -= l * xj.w;
+          T.X4[i] = xi;
+        }
       }
-      DM_SYNC();
     }
+    DM_SYNC();
   }
 }
 
@@ -235,7 +270,7 @@ __device__ __forceinline__ float impedance(const float *si, float x) {
 // ------------------------------------------------------------------------------------------------ stage 1
 __device__ __forceinline__ void stage1(Ctx &c) {
   BTile &T = *c.T;
-  const BallModel &M = model(c);
+  const BallModel FFE_GLOBAL &M = model(c);
   const int lane = c.lane, depth = l_depth(c), parent = l_parent(c), ndof = l_ndof(c);
   const int nchild = (int)(c.lkids >> 24), ch0 = (int)(c.lkids & 0xffu), ch1 = (int)((c.lkids >> 8) & 0xffu), ch2 = (int)((c.lkids >> 16) & 0xffu);
   const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
@@ -320,15 +355,25 @@ __device__ __forceinline__ void stage1(Ctx &c) {
       ftot = ftot - mk6(Tw + cross(r, Fw), Fw);
     }
   }
-  // ---- subtree sums (mj_crb's composite inertia and mj_rne's backward pass), leaves first
+  // ---- subtree sums (mj_crb's composite inertia, then mj_rne's backward pass), leaves first
   I10 crb = cinert;
 #pragma unroll 1
   for (int d = M.maxdepth; d >= 1; d--) {
     if (depth == d) {
-      if (nchild > 0) { const float *p = T.lk[ch0]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
-      if (nchild > 1) { const float *p = T.lk[ch1]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
-      if (nchild > 2) { const float *p = T.lk[ch2]; crb = add10(crb, ld10(p)); ftot = ftot + ld6(p + 10); }
-      st10(T.lk[lane], crb); st6(T.lk[lane] + 10, ftot);
+      if (nchild > 0) crb = add10(crb, ld10(T.lk[ch0]));
+      if (nchild > 1) crb = add10(crb, ld10(T.lk[ch1]));
+      if (nchild > 2) crb = add10(crb, ld10(T.lk[ch2]));
+      st10(T.lk[lane], crb);
+    }
+    DM_SYNC();
+  }
+#pragma unroll 1
+  for (int d = M.maxdepth; d >= 1; d--) {
+    if (depth == d) {
+      if (nchild > 0) ftot = ftot + ld6(T.lk[ch0]);
+      if (nchild > 1) ftot = ftot + ld6(T.lk[ch1]);
+      if (nchild > 2) ftot = ftot + ld6(T.lk[ch2]);
+      st6(T.lk[lane], ftot);
     }
     DM_SYNC();
   }
@@ -507,7 +552,7 @@ __device__ __forceinline__ bool qcqp2(float &x0, float &x1, float A00, float A01
 // ------------------------------------------------------------------------------------------------ stage 2
 __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, float &act_out, bool integrate, int &iters_out, float *qacc_norm2) {
   BTile &T = *c.T;
-  const BallModel &M = model(c);
+  const BallModel FFE_GLOBAL &M = model(c);
   const int lane = c.lane;
   const int nc = c.nc;
   const float h = M.h;
@@ -577,7 +622,10 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
     if (on && p == 0) {
       const float K = T.c_par[k][0], B = T.c_par[k][1], invw = T.c_par[k][2], incl = T.c_par[k][4], dist = T.c_dist[k];
-      const float imp = impedance(M.c_solimp, fabsf(dist - incl));
+      float si_[5];
+#pragma unroll
+      for (int q2 = 0; q2 < 5; q2++) si_[q2] = M.c_solimp[q2];
+      const float imp = impedance(si_, fabsf(dist - incl));
       const float R0 = fmaxf(1e-15f, (1.f - imp) * invw / imp);
       T.c_D[k] = T.c_excl[k] ? 0.f : 1.f / R0;
       T.c_mu[k] = T.c_par[k][3];
@@ -627,7 +675,10 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       if (dlo < 0.f) { lsgn[s] = 1.f; dist = dlo; }
       else if (dhi < 0.f) { lsgn[s] = -1.f; dist = dhi; }
       if (lsgn[s] != 0.f) {
-        const float imp = impedance(M.j_solimp, fabsf(dist));
+        float si_[5];
+#pragma unroll
+        for (int q2 = 0; q2 < 5; q2++) si_[q2] = M.j_solimp[q2];
+        const float imp = impedance(si_, fabsf(dist));
         lD[s] = 1.f / fmaxf(1e-15f, (1.f - imp) * M.s_invw[s][lane] / imp);
         laref[s] = -M.s_B[s][lane] * (lsgn[s] * c.v[s]) - M.s_K[s][lane] * imp * dist;
       }
@@ -1198,7 +1249,6 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     c.sdof[s] = f;
     c.sbl[s] = f >= 0 ? ((unsigned)M.d_blk[f] | ((unsigned)M.d_li[f] << 8)) : 0u;
   }
-  for (int k = lane; k < NSTEP * 16; k += 64) T.piv[k / 16][k % 16] = M.piv[k / 16][k % 16];
   const bool do_reset = (mode == 1) || (mode == 0 && S.needs_reset != 0);
   const bool phys_only = (mode == 2);
   float act_reg = 0.f, ctrl_reg = 0.f;
@@ -1239,7 +1289,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     }
     if (!phys_only) step_counter++;
   }
-  if (lane < 32) T.sens[lane] = 0.f;
+  if (lane < 24) T.sens[lane] = 0.f;
   DM_SYNC();
   const int nsub = phys_only ? nphys : M.nsub;
   float qn2 = 0.f;

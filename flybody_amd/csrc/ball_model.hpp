@@ -32,7 +32,7 @@ using ffe::Tensor;
 constexpr int NL = 64;      // fly links handled by lanes
 constexpr int ND = 102;     // fly hinge dofs (oracle dof index - 3)
 constexpr int NDP = 104;    // padded
-constexpr int NMMAX = 592;  // M entries (582) padded
+constexpr int NMMAX = 584;  // M entries (580) padded
 constexpr int ECAP = 10;    // M entries per lane
 constexpr int NSTEP = 14;   // pivots per block (largest block: abdomen / head tree, 14 dofs)
 constexpr int NBLK = 12;    // independent blocks of M (6 legs, head tree, abdomen, 2 wings, 2 halteres)
@@ -396,6 +396,7 @@ inline BallHost build_ball_model(const Blob &b) {
       if (fill) slot++;
     }
     M.nfs = slot;
+    if (slot + 8 > NFS) throw std::runtime_error("ball model: factor schedule needs padding room");
     slot = 0;
     for (int s = 0; s < NSTEP; s++) {  // pass 1: rows leaf -> root
       int fill = 0;
@@ -408,6 +409,7 @@ inline BallHost build_ball_model(const Blob &b) {
       if (fill) slot++;
     }
     M.np1 = slot;
+    if (slot + 8 > NPS) throw std::runtime_error("ball model: solve schedule needs padding room");
     slot = 0;
     for (int r = 0; r < NSTEP; r++) {  // pass 2: columns root -> leaf
       int fill = 0;
@@ -420,6 +422,7 @@ inline BallHost build_ball_model(const Blob &b) {
       if (fill) slot++;
     }
     M.np2 = slot;
+    if (slot + 8 > NPS) throw std::runtime_error("ball model: solve schedule needs padding room");
     int k = 0;
     for (const Ent &e : ents) {
       int t = k / NL, l = k % NL;
