@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 8192
 ALGO_BYTES_PER_ENV_STEP = 1408  # reads 624 + writes 784 (fp32 state, minimal I/O)
+BALL_ENVS_PER_GPU = 4096        # BASELINE.json configs[2]: walk_on_ball, contacts + solver, batch 4096 on one MI355X
+BALL_ALGO_BYTES_PER_ENV_STEP = 4412  # reads 1740 + writes 2672
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -54,7 +56,27 @@ def _cpu_worker(args):
     return steps, time.perf_counter() - t0
 
 
-def cpu_baseline(target_seconds=20.0):
+def _cpu_worker_ball(args):
+    """walk_on_ball twin of `_cpu_worker` (raw actions U(-0.2, 0.2), BASELINE configs[0] / [2])."""
+    idx, steps = args
+    import numpy as np
+
+    from oracle import oracle as O
+
+    m = O.OracleModel(os.path.join(ROOT, "flybody_amd", "assets", "fly_ball.ffmb"))
+    env = O.OracleBallEnv(m)
+    env.reset()
+    rng = np.random.RandomState(idx)
+    acts = rng.uniform(-0.2, 0.2, (steps, 59))
+    for k in range(10):
+        env.step(acts[k])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(acts[k])
+    return steps, time.perf_counter() - t0
+
+
+def cpu_baseline(target_seconds=20.0, workload="flight_imitation"):
     """Oracle ("port") on all host cores, one env per process as the reference runs its actors
     (train_dmpo_ray.py:432-452).  Must run before this process touches the GPU (fork)."""
     import multiprocessing as mp
@@ -65,17 +87,18 @@ def cpu_baseline(target_seconds=20.0):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # a one-GPU box shares its host: stay within the 16-core share unless told otherwise
     cores = max(1, min(cores, int(os.environ.get("FLYBODY_BENCH_CORES", "16"))))
-    steps, dt = _cpu_worker((0, 1500))
+    worker = _cpu_worker_ball if workload == "walk_on_ball" else _cpu_worker
+    steps, dt = worker((0, 100 if workload == "walk_on_ball" else 1500))
     per_core = steps / dt
-    n = int(max(500, 0.7 * per_core * target_seconds))
+    n = int(max(50 if workload == "walk_on_ball" else 500, 0.7 * per_core * target_seconds))
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(i, n) for i in range(cores)])
+        res = pool.map(worker, [(i, n) for i in range(cores)])
     wall = max(r[1] for r in res)
     value = sum(r[0] for r in res) / wall
     return {"value": round(value, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} processes x 1 float64 oracle env x {n} control steps of the same flight-imitation workload "
+            "sample": f"{cores} processes x 1 float64 oracle env x {n} control steps of the same {workload} workload "
                       f"(single-core {per_core:.0f} env-steps/s; pool wall {time.perf_counter() - t0:.1f}s)"}
 
 
@@ -116,9 +139,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("flight_imitation", "walk_on_ball"), default="flight_imitation",
+                    help="flight_imitation = the headline metric (BASELINE configs[3]/[4]); walk_on_ball = configs[2]")
     args = ap.parse_args()
+    ball = args.workload == "walk_on_ball"
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = BALL_ENVS_PER_GPU if ball else ENVS_PER_GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,7 +158,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()  # before any GPU initialisation (uses fork)
+        cpu = cpu_baseline(workload=args.workload)  # before any GPU initialisation (uses fork)
 
     import torch
     import torch.distributed as dist
@@ -156,10 +184,15 @@ def main():
     else:
         from flybody_amd import fly_envs
 
-        env = fly_envs.flight_imitation(batch_size=B, device=local_rank, random_state=0, env_id_base=env_id_base)
+        if ball:
+            env = fly_envs.walk_on_ball(batch_size=B, device=local_rank)
+        else:
+            env = fly_envs.flight_imitation(batch_size=B, device=local_rank, random_state=0, env_id_base=env_id_base)
     spec = env.action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
     hi = torch.tensor(spec.maximum, device=dev)
+    if ball:  # BASELINE configs[2]: raw actions U(-0.2, 0.2)^59 (`task_utils.py:13-24`)
+        lo, hi = torch.full_like(lo, -0.2), torch.full_like(hi, 0.2)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     npool = 16
     acts = [(lo + (hi - lo) * torch.rand(B, spec.shape[0], device=dev, generator=g)).contiguous() for _ in range(npool)]
@@ -220,7 +253,7 @@ def main():
         # upper bound here, since these are 4-byte-per-lane reads, not the wide streams the x2 was calibrated on)
         traffic, traffic_src = None, None
         pj = os.path.join(ROOT, "profiles", "r01_pmc_final_kernel.json")
-        if os.path.exists(pj) and B == ENVS_PER_GPU and not fake:
+        if os.path.exists(pj) and B == ENVS_PER_GPU and not fake and not ball:
             with open(pj) as f:
                 pm = json.load(f)
             if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
@@ -228,19 +261,22 @@ def main():
                 traffic_src = "profiles/r01_pmc_final_kernel.json (2*FETCH_SIZE + WRITE_SIZE, per launch)"
         total_env_steps = world * B * args.steps
         value = total_env_steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * B / (k_ms * 1e-3) / 1e9
+        algo = BALL_ALGO_BYTES_PER_ENV_STEP if ball else ALGO_BYTES_PER_ENV_STEP
+        achieved = algo * B / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/sec (whole node), fruitfly flight-imitation task",
+            "metric": "env-steps/sec (whole node), fruitfly " + ("walk_on_ball task" if ball else "flight-imitation task"),
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "flight_imitation (BASELINE configs[3]): 4 substeps @5e-5 s + WBPG + obs/reward/termination/auto-reset",
+            "config": {"workload": ("walk_on_ball (BASELINE configs[2]): 10 substeps @2e-4 s, ball contacts (elliptic cones, Newton + noslip), adhesion, "
+                                    "filtered actuators, touch/force sensors, obs/reward/termination/auto-reset") if ball else
+                                   "flight_imitation (BASELINE configs[3]): 4 substeps @5e-5 s + WBPG + obs/reward/termination/auto-reset",
                        "envs_per_gpu": B, "global_batch": world * B, "parallelism": f"env-sharded x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
-                       "actions": "uniform over the raw action spec (canonical U(-1,1)), resident in HBM"},
+                       "actions": "raw U(-0.2, 0.2)^59, resident in HBM" if ball else "uniform over the raw action spec (canonical U(-1,1)), resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "flight_step_kernel", "kernel_ms": round(k_ms, 4),
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
+                         "kernel": "ball_step_kernel" if ball else "flight_step_kernel", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": algo * B,
                          "note": "fused wave-per-env step keeps state on chip; VALU/LDS-latency bound, not HBM bound (DESIGN.md)"},
             "physics_substeps_per_s": round(value * env.spec.nsub, 1),
         }

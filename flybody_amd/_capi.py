@@ -58,6 +58,10 @@ def lib():
                 "flybody_amd has no CPU fallback.") from e
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing; flybody_amd has no CPU fallback.")
+    try:  # PyTorch-ROCm bundles its own HIP runtime: load it first so this library binds to the same copy (two HIP
+        import torch  # noqa: F401   runtimes in one process do not see each other's devices)
+    except Exception:  # noqa: BLE001
+        pass
     L = C.CDLL(LIB_PATH)
     vp, fp, ip, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
     L.ffe_create_flight.restype = C.c_int

@@ -102,7 +102,7 @@ struct Ctx {
   int nc;
   float aws[3];           // warm start of the constraint solver: last substep's solution
   V3 abws;
-  int have_ws;
+  int have_ws, overflow;
 #ifdef FFB_STAMPS
   unsigned long long st_t0, st_acc[24];
 #endif
@@ -451,6 +451,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   const unsigned long long bal = __ballot(hit);
   const int idx = __popcll(bal & ((1ull << lane) - 1ull));
   c.nc = min(__popcll(bal), NC);
+  if (__popcll(bal) > NC) c.overflow = 1;  // more contacts than the tile holds: the extra ones are dropped and the env is flagged
   if (hit && idx < NC) {
     T.c_link[idx] = lane;
     const int last = ndof == 1 ? c.sdof[0] : (ndof == 2 ? c.sdof[1] : c.sdof[2]);
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   const BallModel &M = *Mp;
   BState &S = states[env];
   Ctx c;
-  c.M = Mp; c.T = &T; c.lane = lane; c.flags = K.flags;
+  c.M = Mp; c.T = &T; c.lane = lane; c.flags = K.flags; c.overflow = 0;
 #ifdef FFB_STAMPS
   c.st_t0 = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < 24; k++) c.st_acc[k] = 0;
@@ -1314,6 +1315,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
     S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc;
+    if (do_reset) S.overflow = 0; else if (c.overflow) S.overflow = 1;
     S.have_ws = do_reset ? 0 : c.have_ws; S.ballacc_ws[0] = c.abws.x; S.ballacc_ws[1] = c.abws.y; S.ballacc_ws[2] = c.abws.z;
   }
 #ifdef FFB_STAMPS
