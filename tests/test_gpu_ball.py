@@ -249,3 +249,28 @@ def test_config3_batch_rollout_properties(torch_mod):
     r = ts.reward
     assert float(r.min()) >= 0.0 and float(r.max()) <= 1.0
     env.close()
+
+
+def test_config1_single_env_1000_random_steps(torch_mod):
+    """BASELINE configs[0]: walk_on_ball, 1 env, 1000 random-action control steps (raw U(-0.2, 0.2), `task_utils.py:13-24`).
+    The episode runs to the 2.0 s time limit: MID for 999 steps, LAST (discount 1) on step 1000, FIRST on the next call."""
+    from flybody_amd import fly_envs
+
+    torch = torch_mod
+    env = fly_envs.walk_on_ball(batch_size=1)
+    ts = env.reset()
+    assert int(ts.step_type[0]) == 0
+    g = torch.Generator(device="cuda").manual_seed(0)
+    total = 0.0
+    for k in range(1000):
+        ts = env.step((torch.rand(1, 59, device="cuda", generator=g) * 0.4 - 0.2).contiguous())
+        st = int(ts.step_type[0])
+        assert st == (2 if k == 999 else 1), (k, st)
+        total += float(ts.reward[0])
+    assert float(ts.discount[0]) == 1.0 and torch.isfinite(env.flat_observation).all()
+    assert 0.0 < total / 1000 < 1.0
+    ts = env.step(torch.zeros(1, 59, device="cuda"))
+    assert int(ts.step_type[0]) == 0 and float(ts.reward[0]) == 0.0
+    ints, _ = env.get_task_state()
+    assert int(ints[0, 7]) == 0  # no contact overflow
+    env.close()
