@@ -131,7 +131,7 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
   BTile &T = *c.T;
   const BallModel FFE_GLOBAL &M = model(c);
   const int lane = c.lane;
-#pragma unroll 2
+#pragma unroll
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
     if (ea >> 31) {
@@ -167,13 +167,13 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
     }
   }
   DM_SYNC();
-#pragma unroll 2
+#pragma unroll
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
     if ((ea >> 31) && (ea & 0xffu) == ((ea >> 8) & 0xffu)) dinv[ea & 0xffu] = frcp(dst[(ea >> 16) & 0x3ffu]);
   }
   DM_SYNC();
-#pragma unroll 2
+#pragma unroll
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
     if ((ea >> 31) && (ea & 0xffu) != ((ea >> 8) & 0xffu)) dst[(ea >> 16) & 0x3ffu] *= dinv[ea & 0xffu];
@@ -282,6 +282,14 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
     jpos[s] = {M.s_jpos[0][s][lane], M.s_jpos[1][s][lane], M.s_jpos[2][s][lane]};
   }
+  // joint rotations (about the link-frame axes) once, outside the level sweep
+  Q4 jq[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    float sn, cs;
+    sincosf(0.5f * c.q[s], &sn, &cs);
+    jq[s] = {cs, axis[s].x * sn, axis[s].y * sn, axis[s].z * sn};
+  }
   // ---- mj: mj_kinematics, one tree level per sweep
   V3 axw[3], anc[3];
 #pragma unroll 1
@@ -297,7 +305,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
         if (s < ndof) {
           anc[s] = xp + qrot(xq, jpos[s]);
           axw[s] = qrot(xq, axis[s]);
-          xq = qmul(xq, axis_angle(axis[s], c.q[s]));
+          xq = qmul(xq, jq[s]);
           xp = anc[s] - qrot(xq, jpos[s]);
         }
       }
@@ -417,7 +425,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   }
   if (c.xh) { st6(T.F[c.sdof[2]], S6{M.x_M[lane], 0.f, 0.f, 0.f, 0.f, 0.f}); st6(T.C[c.sdof[2]], S6{1.f, 0.f, 0.f, 0.f, 0.f, 0.f}); }
   DM_SYNC();
-#pragma unroll 2
+#pragma unroll
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
     if (ea >> 31) {
@@ -705,7 +713,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       for (int s = 0; s < 3; s++) if (slot_on(c, s)) { a[s] = c.aws[s]; T.X4[opq(c.sdof[s])].x = a[s]; T.dadd[opq(c.sdof[s])] = 0.f; }
       ab = c.abws;
       DM_SYNC();
-#pragma unroll 2
+#pragma unroll
       for (int t = 0; t < ECAP; t++) {
         const unsigned ea = M.ent_a[t][lane];
         if (ea >> 31) {
@@ -813,7 +821,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       BSTAMP(9);  // newton: gradient
       // H_ff = M + diag(limit D) + sum_c J_f' Hc J_f  (same sparsity as M: a contact row only spans one chain)
       DM_SYNC();
-#pragma unroll 1
+#pragma unroll 2
       for (int t = 0; t < ECAP; t++) {
         const unsigned ea = M.ent_a[t][lane], eb = M.ent_b[t][lane];
         if (ea >> 31) {
