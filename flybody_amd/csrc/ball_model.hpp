@@ -6,11 +6,12 @@
 //   lanes <-> the 64 fly links that carry legs, head, mouth, antennae, wings and abdomen (body space work);
 //            each lane also owns the <= 3 hinge dofs of its link (joint space work);
 //   the two halteres (single hinges on the fixed thorax, no collision geoms, no actuators) are closed-form
-//            one-dof systems evaluated by lanes 0 and 1 in an extra dof slot;
+//            one-dof systems parked in a free dof slot of two lanes;
 //   the ball is a sphere spinning about its fixed centre: isotropic inertia, no bias force, closed-form drag;
 //            it only couples to the legs through the contact rows;
-//   lanes <-> entries of the joint-space inertia (582 non-zeros, <= 10 per lane) for assembly, the block
-//            factorisation (12 independent blocks, 14 lock-step pivots) and the triangular solves.
+//   the joint-space inertia (580 non-zeros in 12 independent blocks) lives in LDS, so any lane can touch any entry:
+//            assembly, the block factorisation and the triangular solves follow host-built schedules of
+//            64-wide slots (fac_a/fac_b, p1, p2, ent_a/ent_b below).
 // All tables are lane-major ([field][lane]) so a wavefront's read is one coalesced transaction.
 #pragma once
 
@@ -62,14 +63,14 @@ struct BallModel {
   int l_touch[NL], l_force[NL], l_adh[NL];  // sensor / adhesion-actuator index carried by this link, or -1
   float l_fsite[4][NL];                     // force-sensor site orientation in the link frame
   int l_chain[NCH][NL], l_nchain[NL];       // fly dofs from the chain root down to this link's last dof
-  // ---- dof slots (slot s of lane = s-th hinge of the link); slot 3 = haltere on lanes 0, 1
+  // ---- dof slots (slot s of lane = s-th hinge of the link); x_on lanes carry a haltere in slot 2 (arrays keep 4 slots)
   int s_dof[4][NL];
   float s_axis[3][3][NL], s_jpos[3][3][NL];
   float s_stiff[4][NL], s_sref[4][NL], s_damp[4][NL], s_arm[4][NL], s_lo[4][NL], s_hi[4][NL], s_invw[4][NL], s_K[4][NL], s_B[4][NL],
       s_solimp[5][4][NL];
   int s_limited[4][NL], s_act[2][4][NL];  // s_act[0]: joint actuator id, s_act[1]: tendon actuator id (or -1)
   float s_actcoef[2][4][NL];
-  // halteres (lanes 0, 1): constant inertia, gravity torque Gc cos q + Gs sin q, drag -cv qd - cq |qd| qd
+  // halteres (x_on lanes): constant inertia, gravity torque Gc cos q + Gs sin q, drag -cv qd - cq |qd| qd
   float x_M[NL], x_Gc[NL], x_Gs[NL], x_cv[NL], x_cq[NL];
   int x_on[NL];  // lane carries a haltere in slot 2
   // ---- ball
@@ -78,18 +79,12 @@ struct BallModel {
   short d_parent[NDP], d_madr[NDP], d_blk[NDP], d_li[NDP];
   unsigned short d_amask[NDP];
   float d_arm[NDP];
-  unsigned int e_meta[ECAP][NL];    // entry: i | j << 8 | li_i << 16 | li_j << 20 | blk << 24 | valid << 31
-  unsigned short e_adr[ECAP][NL];   // address in the M layout
-  unsigned short e_fmask[ECAP][NL]; // factor: bit s set when pivot step s updates this entry
-  unsigned char e_rowstep[ECAP][NL], e_colstep[ECAP][NL];  // solve passes: the step at which the entry fires
   // Schedules (any lane may process any entry: the matrices live in LDS).  One slot = up to 64 independent updates.
   //   fac_a: adr_e | adr_kk << 10 | adr_ki << 20 | valid << 31, fac_b: adr_kj      L[e] -= L[ki] L[kj] / L[kk]
   //   p1 / p2: adr_e | i << 10 | j << 17 | valid << 31                              x[j] -= L[e] x[i]  /  x[i] -= L[e] x[j]
   //   ent_a: i | j << 8 | adr << 16 | valid << 31, ent_b: blk | li_i << 4 | li_j << 8 (assembly, final scaling)
   unsigned fac_a[NFS][NL], fac_b[NFS][NL], p1[NPS][NL], p2[NPS][NL], ent_a[ECAP][NL], ent_b[ECAP][NL];
   int nfs, np1, np2;
-  unsigned int piv[NSTEP][NBLK + 4];  // pivot of block b at step s: madr | amask << 16 ... (0xffffffff = none)
-  unsigned char piv_dof[NSTEP][NBLK + 4];
   // ---- actuators (lane = actuator)
   int a_trn[NL], a_nwrap[NL], a_wdof[NWRAP][NL], a_action[NL], a_link[NL];
   float a_wcoef[NWRAP][NL], a_gain[NL], a_b0[NL], a_b1[NL], a_b2[NL], a_clo[NL], a_chi[NL], a_flo[NL], a_fhi[NL], a_tau[NL];
@@ -335,16 +330,7 @@ inline BallHost build_ball_model(const Blob &b) {
   for (int l = 0; l < NL; l++) if (M.x_on[l]) M.d_arm[M.s_dof[2][l]] = 0.f;  // x_M already holds the haltere armature
   M.nM = adr; M.nblk = nblk;
   blk_start.push_back(ND);
-  for (int s = 0; s < NSTEP; s++) for (int bb = 0; bb < NBLK + 4; bb++) { M.piv[s][bb] = 0xffffffffu; M.piv_dof[s][bb] = 255; }
-  for (int bb = 0; bb < nblk; bb++) {
-    int n = blk_start[bb + 1] - blk_start[bb];
-    for (int s = 0; s < n; s++) {
-      int k = blk_start[bb + 1] - 1 - s;
-      M.piv[s][bb] = (unsigned)madr[k] | (amask[k] << 16);
-      M.piv_dof[s][bb] = (unsigned char)k;
-    }
-  }
-  // entries -> lanes: greedy, heaviest (most pivot updates) first onto the least loaded lane
+  // entries of M with the elimination steps that touch them
   struct Ent { int i, j, adr, work; unsigned short fmask; int rowstep, colstep; };
   std::vector<Ent> ents;
   for (int i = 0; i < ND; i++) {
@@ -361,23 +347,6 @@ inline BallHost build_ball_model(const Blob &b) {
       ents.push_back(e);
       j = par[j]; a++;
     }
-  }
-  std::vector<int> order(ents.size());
-  for (size_t k = 0; k < order.size(); k++) order[k] = (int)k;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return ents[a].work > ents[c].work; });
-  std::vector<int> load(NL, 0), cnt(NL, 0);
-  for (int idx : order) {
-    int best = -1;
-    for (int l = 0; l < NL; l++) if (cnt[l] < ECAP && (best < 0 || load[l] < load[best])) best = l;
-    if (best < 0) throw std::runtime_error("ball model: M entries do not fit the lanes");
-    const Ent &e = ents[idx];
-    int t = cnt[best]++;
-    load[best] += e.work + 1;
-    M.e_meta[t][best] = (unsigned)e.i | ((unsigned)e.j << 8) | ((unsigned)li[e.i] << 16) | ((unsigned)li[e.j] << 20) | ((unsigned)blk[e.i] << 24) | 0x80000000u;
-    M.e_adr[t][best] = (unsigned short)e.adr;
-    M.e_fmask[t][best] = e.fmask;
-    M.e_rowstep[t][best] = (unsigned char)e.rowstep;
-    M.e_colstep[t][best] = (unsigned char)e.colstep;
   }
   // ---- schedules
   {
