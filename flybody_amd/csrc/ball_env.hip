@@ -49,7 +49,7 @@ constexpr float kLsTol = 1e-3f;  // |phi'(alpha)| <= tol |phi'(0)|: an inexact l
 struct alignas(16) BState {
   float q[NDP], v[NDP], act[64];
   float ballq[4], ballw[4];
-  float qacc_ws[NDP], ballacc_ws[4];  // previous constraint-solver solution (mj: qacc_warmstart)
+  float qacc_ws[NDP], wsc[NL][3];  // warm start of the constraint solver: last limit force per dof, last contact force per link
   int step_counter, needs_reset, overflow, iters, ncon, have_ws, pad[2];
 };
 
@@ -59,16 +59,22 @@ struct BTaskDev {
 
 struct alignas(16) BTile {
   union {
-    struct { float Q[NDP], V[NDP]; };  // joint state staged for the actuators / contact rows (start of stage 2) and the observation
-    float4 X4[NDP];                     // right-hand sides / solutions of the block solves (from the smooth solve on)
+    struct {
+      union {
+        struct { float Q[NDP], V[NDP]; };  // joint state staged for the actuators / contact rows (start of stage 2) and the observation
+        float4 X4[NDP];                     // right-hand sides / solutions of the block solves (from the smooth solve on)
+      };
+      float Lh[NMMAX], dinv_h[NDP];         // factor of M + h B (Euler)
+    };
+    float S[RMAX][RMAX + 1];                // Newton: I + L' G L and its Cholesky factor (no block solve is in flight then)
   };
-  float Mq[NMMAX], Lm[NMMAX], Lh[NMMAX];
-  float dinv_m[NDP], dinv_h[NDP], dadd[NDP];
+  float Mq[NMMAX], Lm[NMMAX];
+  float dinv_m[NDP], dadd[NDP];
   float C[NDP][6];
   union {
-    float F[NDP][6];    // crb * cdof during the inertia assembly
-    float lk[NL][12];   // link exchange of the level sweeps: pose (7) | velocity + acceleration (12) | crb (10) | force (6)
-    struct { float A[2 * NC][2 * NC + 1], b[2 * NC], f[2 * NC]; } ns;  // noslip: unregularised tangential block
+    float F[NDP][6];           // crb * cdof during the inertia assembly
+    float lk[NL][12];          // link exchange of the level sweeps: pose (7) | velocity + acceleration (12) | crb (10) | force (6)
+    float G[RMAX][RMAX + 1];   // stage 2: G = J M^-1 J' over the constraint rows (until the sensor sweeps)
   };
   float frc[64];
   int c_link[NC], c_blk[NC], c_excl[NC], c_nch[NC], c_adh[NC];
@@ -76,8 +82,12 @@ struct alignas(16) BTile {
   unsigned char c_chain[NC][16];
   float c_par[NC][5];  // K, B, invweight, friction, includemargin
   float c_pos[NC][3], c_frame[NC][9], c_dist[NC];
-  float c_J[NC][3][NCH], c_JB[NC][3][NCH], c_Jb[NC][3][3], c_JBb[NC][3][3];
-  float c_D[NC], c_mu[NC], c_aref[NC][3], c_f[NC][3], c_Hc[NC][9], c_jar[NC][3], c_jd[NC][3], c_w[NC][3];
+  float c_J[NC][3][NCH], c_Jb[NC][3][3];
+  float c_D[NC], c_mu[NC], c_aref[NC][3], c_f[NC][3], c_w[NC][3];
+  // constraint rows: 3 per contact (normal, two tangents), then the instantiated joint limits
+  float r_y0[RMAX], r_lam[RMAX], r_f[RMAX], r_y[RMAX], r_e[RMAX], r_d[RMAX], r_jd[RMAX], r_u[RMAX], r_L[RMAX][3];
+  float r_sgn[RMAX], r_D[RMAX];
+  unsigned char r_blk[RMAX], r_col[RMAX], r_dof[RMAX], rowof[16][12];
   float sens[24];  // running sums of the buffered sensors: force 18, touch 6
 };
 
@@ -100,8 +110,7 @@ struct Ctx {
   Q4 bq;
   V3 bw, btau;
   int nc;
-  float aws[3];           // warm start of the constraint solver: last substep's solution
-  V3 abws;
+  float wsl[3], wsc[3];   // warm start of the constraint solver: last substep's limit force per slot, contact force of this link
   int have_ws, overflow;
 #ifdef FFB_STAMPS
   unsigned long long st_t0, st_acc[24];
@@ -693,244 +702,262 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       }
     }
   }
-  // ---- mj: mj_fwdConstraint - Newton on 1/2 (a - a_s)' M (a - a_s) + s(J a - aref), started at a_s
-  float a[3], Ma[3];
+  // ---- mj: mj_fwdConstraint in the space of the constraint rows.  With Y = M^-1 J', G = J Y and a = a_s + Y lambda the
+  //      primal cost 1/2 (a - a_s)' M (a - a_s) + s(J a - aref) becomes 1/2 lambda' G lambda + s(y0 + G lambda), y0 = J a_s - aref;
+  //      its Newton step is  d = -(I + W G)^-1 (lambda - f),  W = d2s/dy2 (3x3 per contact, scalar per limit).  M is factorised
+  //      once per substep (stage 1); the rows' columns of G come four per block solve, rows of different blocks sharing a
+  //      column because M^-1 is block diagonal; every Newton iteration is then dense work on <= 32 rows.
+  int lrow[3] = {-1, -1, -1};
+  const int nrc = 3 * nc;
+  int R = nrc;
+  {  // limit rows: one per instantiated limit, in (slot, lane) order
 #pragma unroll
-  for (int s = 0; s < 3; s++) { a[s] = am[s]; Ma[s] = qs[s]; }
-  V3 ab = amb;
-  const bool warm = c.have_ws != 0;
-  int any_lim = 0;
-#pragma unroll
-  for (int s = 0; s < 3; s++) any_lim |= (lsgn[s] != 0.f);
-  int nact = 0;
-  for (int k = 0; k < nc; k++) nact += T.c_excl[k] ? 0 : 1;
-  const bool constrained = __any(any_lim) || nact > 0;
+    for (int s = 0; s < 3; s++) {
+      const bool on = lsgn[s] != 0.f;
+      const unsigned long long bal = __ballot(on);
+      const int idx = R + __popcll(bal & ((1ull << lane) - 1ull));
+      if (on && idx < RMAX) {
+        lrow[s] = idx;
+        T.r_sgn[idx] = lsgn[s]; T.r_D[idx] = lD[s]; T.r_dof[idx] = (unsigned char)opq(c.sdof[s]); T.r_blk[idx] = (unsigned char)(opq(c.sbl[s]) & 0xffu);
+        T.r_y0[idx] = lsgn[s] * am[s] - laref[s];
+        T.r_lam[idx] = c.have_ws ? c.wsl[s] : 0.f;
+      }
+      R += __popcll(bal);
+    }
+    if (R > RMAX) { R = RMAX; c.overflow = 1; }
+  }
+  const bool constrained = R > 0;
   int iters = 0;
-  float lf[3] = {0.f, 0.f, 0.f};
-  if (constrained) {
-    if (warm) {  // mj: qacc_warmstart.  M a of the starting point by one pass over M's entries (LDS float adds)
+  if (lane < nrc) { T.r_blk[lane] = (unsigned char)T.c_blk[lane / 3]; }
+  for (int k = lane; k < 16 * 12; k += 64) (&T.rowof[0][0])[k] = 255;
+  DM_SYNC();
+  // contact rows: y0 = J a_s - aref (row-parallel), warm start from the force this link's contact carried last substep
 #pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) { a[s] = c.aws[s]; T.X4[opq(c.sdof[s])].x = a[s]; T.dadd[opq(c.sdof[s])] = 0.f; }
-      ab = c.abws;
-      DM_SYNC();
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = am[s];
+  if (c.have_ws) { for (int k = 0; k < nc; k++) if (T.c_link[k] == lane) { T.r_lam[3 * k] = c.wsc[0]; T.r_lam[3 * k + 1] = c.wsc[1]; T.r_lam[3 * k + 2] = c.wsc[2]; } }
+  else if (lane < nrc) T.r_lam[lane] = 0.f;
+  DM_SYNC();
+  for (int base = 0; base < nc; base += 4) {
+    const int k = base + (lane >> 4), p = lane & 15;
+    const bool on = k < nc;
+    const bool pv = on && p < T.c_nch[k];
+    const float av = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
 #pragma unroll
-      for (int t = 0; t < ECAP; t++) {
-        const unsigned ea = M.ent_a[t][lane];
-        if (ea >> 31) {
-          const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu;
-          const float mv_ = T.Mq[(ea >> 16) & 0x3ffu];
-          atomicAdd(&T.dadd[i], mv_ * T.X4[j].x);
-          if (i != j) atomicAdd(&T.dadd[j], mv_ * T.X4[i].x);
+    for (int r = 0; r < 3; r++) {
+      float y = row_sum(pv ? T.c_J[k][r][p] * av : 0.f);
+      if (on && p == 0) T.r_y0[3 * k + r] = y + T.c_Jb[k][r][0] * amb.x + T.c_Jb[k][r][1] * amb.y + T.c_Jb[k][r][2] * amb.z - T.c_aref[k][r];
+    }
+  }
+  // columns: a row's column is its rank among the rows of its block
+  int ncol;
+  {
+    int mycol = 0;
+    if (lane < R) {
+      const int b = T.r_blk[lane];
+      for (int r2 = 0; r2 < lane; r2++) mycol += (T.r_blk[r2] == b);
+      T.r_col[lane] = (unsigned char)mycol;
+      if (mycol < 12) T.rowof[b][mycol] = (unsigned char)lane; else c.overflow = 1;
+      mycol += 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mycol = max(mycol, __shfl_xor(mycol, off));
+    ncol = min(mycol, 12);
+  }
+  DM_SYNC();
+  // G: ball coupling between contact rows, then the fly part M_blk^-1 from the block solves
+  if (lane < R) {
+    for (int r2 = 0; r2 < R; r2++) {
+      float gv = 0.f;
+      if (lane < nrc && r2 < nrc) {
+        const float *ja = T.c_Jb[lane / 3][lane % 3], *jb = T.c_Jb[r2 / 3][r2 % 3];
+        gv = (ja[0] * jb[0] + ja[1] * jb[1] + ja[2] * jb[2]) / Ib;
+      }
+      T.G[lane][r2] = gv;
+    }
+  }
+#pragma unroll 1
+  for (int cb = 0; cb < ncol; cb += 4) {
+    for (int f = lane; f < ND; f += 64) T.X4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+    DM_SYNC();
+    for (int item = lane; item < nrc * NCH; item += 64) {  // contact rows: J' over the chain
+      const int r = item / NCH, p = item - r * NCH, k = r / 3, col = (int)T.r_col[r] - cb;
+      if (col >= 0 && col < 4 && p < T.c_nch[k]) (&T.X4[T.c_chain[k][p]].x)[col] = T.c_J[k][r - 3 * k][p];
+    }
+    if (lane >= nrc && lane < R) {
+      const int col = (int)T.r_col[lane] - cb;
+      if (col >= 0 && col < 4) (&T.X4[T.r_dof[lane]].x)[col] = T.r_sgn[lane];
+    }
+    DM_SYNC();
+    solve4(c, T.Lm, T.dinv_m);
+    if (lane < R) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < nrc) {
+        const int k = lane / 3, r = lane - 3 * k, nch = T.c_nch[k];
+        for (int p = 0; p < nch; p++) {
+          const float jv = T.c_J[k][r][p];
+          const float4 y = T.X4[T.c_chain[k][p]];
+          acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
+        }
+      } else {
+        const float sg = T.r_sgn[lane];
+        const float4 y = T.X4[T.r_dof[lane]];
+        acc = make_float4(sg * y.x, sg * y.y, sg * y.z, sg * y.w);
+      }
+      const int b = T.r_blk[lane];
+#pragma unroll
+      for (int q2 = 0; q2 < 4; q2++) {
+        const int cc = cb + q2;
+        if (cc < 12) {
+          const int r2 = T.rowof[b][cc];
+          if (r2 != 255) T.G[lane][r2] += (q2 == 0 ? acc.x : (q2 == 1 ? acc.y : (q2 == 2 ? acc.z : acc.w)));
         }
       }
-      DM_SYNC();
-#pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) Ma[s] = T.dadd[opq(c.sdof[s])];
-      DM_SYNC();
     }
+    DM_SYNC();
+  }
+  BSTAMP(8);  // constraint rows + G
+  const float scale2 = [&]() { float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 3; s++) if (slot_on(c, s)) sq += qs[s] * am[s];
+    return wave_sum(sq) + dot(qsb, amb); }();
+  if (constrained) {
+    // Dense Newton on <= 32 rows, lane = row, everything in registers: the lane's row of G and of S = I + L' G L, other
+    // lanes' scalars by v_readlane (uniform index), neighbours' by DPP / bpermute shifts.  Loops are fully unrolled over
+    // RMAX with uniform early exits so that the register arrays keep static indices.
+    float Gr[RMAX], Sr[RMAX];
+#pragma unroll
+    for (int j = 0; j < RMAX; j++) Gr[j] = (lane < R && j < R) ? T.G[lane][j] : 0.f;
+    float lam = lane < R ? T.r_lam[lane] : 0.f;
+    const float y0v = lane < R ? T.r_y0[lane] : 0.f;
+    const bool crow = lane < nrc;           // contact row (else limit row or idle lane)
+    const int sub = crow ? lane % 3 : 0;    // position inside the contact's 3-row block
+    auto gdot = [&](float vreg) {           // (G v)[lane], v given as one value per lane
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < RMAX; j++) acc += Gr[j] * rl_f(vreg, j);  // Gr[j] = 0 beyond the R live rows
+      return acc;
+    };
+    float fv = 0.f, yv = 0.f;
+    float L0 = 0.f, L1 = 0.f, L2 = 0.f;  // this row of the block-lower Cholesky factor of W: L[row][first .. first+2]
+    auto eval = [&](float y, bool want_L) {
+      // a contact's three rows are evaluated on all three lanes (the residuals come by shifts inside the block)
+      const float ya = __shfl(y, lane - sub), yb = __shfl(y, lane - sub + 1), yc = __shfl(y, lane - sub + 2);
+      float f = 0.f;
+      if (want_L) L0 = L1 = L2 = 0.f;
+      if (crow) {
+        const int k = lane / 3;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, Hc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], ya, yb, yc, f0, f1, f2, want_L ? Hc : nullptr);
+        f = sub == 0 ? f0 : (sub == 1 ? f1 : f2);
+        if (want_L) {  // Hc = L L' (positive semi-definite: a vanishing pivot zeroes its column)
+          const float l00 = Hc[0] > 1e-30f ? sqrtf(Hc[0]) : 0.f, i00 = l00 > 0.f ? 1.f / l00 : 0.f;
+          const float l10 = Hc[3] * i00, l20 = Hc[6] * i00;
+          const float d1 = Hc[4] - l10 * l10, l11 = d1 > 1e-7f * Hc[4] ? sqrtf(d1) : 0.f, i11 = l11 > 0.f ? 1.f / l11 : 0.f;
+          const float l21 = (Hc[7] - l20 * l10) * i11;
+          const float d2 = Hc[8] - l20 * l20 - l21 * l21, l22 = d2 > 1e-7f * Hc[8] ? sqrtf(d2) : 0.f;
+          if (sub == 0) { L0 = l00; } else if (sub == 1) { L0 = l10; L1 = l11; } else { L0 = l20; L1 = l21; L2 = l22; }
+        }
+      } else if (lane < R) {
+        const float D = T.r_D[lane];
+        f = y < 0.f ? -D * y : 0.f;
+        if (want_L) L0 = y < 0.f ? sqrtf(D) : 0.f;
+      }
+      return f;
+    };
 #pragma unroll 1
     for (int it = 0; it < kMaxNewton; it++) {
-      // contact residuals, forces, local Hessians (lane = contact)
-#pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = a[s];
-      DM_SYNC();
-      for (int base = 0; base < nc; base += 4) {
-        const int k = base + (lane >> 4), p = lane & 15;
-        const bool on = k < nc;
-        const bool pv = on && p < T.c_nch[k];
-        const float av = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
-        const float x0 = pv ? T.c_J[k][0][p] : 0.f, x1 = pv ? T.c_J[k][1][p] : 0.f, x2 = pv ? T.c_J[k][2][p] : 0.f;
-        float jar[3] = {row_sum(x0 * av), row_sum(x1 * av), row_sum(x2 * av)};
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, Hc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (on) {
-#pragma unroll
-          for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[k][r][0] * ab.x + T.c_Jb[k][r][1] * ab.y + T.c_Jb[k][r][2] * ab.z - T.c_aref[k][r];
-          if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], jar[0], jar[1], jar[2], f0, f1, f2, Hc);
-          if (p == 0) {
-            T.c_jar[k][0] = jar[0]; T.c_jar[k][1] = jar[1]; T.c_jar[k][2] = jar[2];
-            T.c_f[k][0] = f0; T.c_f[k][1] = f1; T.c_f[k][2] = f2;
-            for (int q2 = 0; q2 < 9; q2++) T.c_Hc[k][q2] = Hc[q2];
-          }
-          if (pv) {  // JB = Hc J, this lane's chain column
-            T.c_JB[k][0][p] = Hc[0] * x0 + Hc[1] * x1 + Hc[2] * x2;
-            T.c_JB[k][1][p] = Hc[3] * x0 + Hc[4] * x1 + Hc[5] * x2;
-            T.c_JB[k][2][p] = Hc[6] * x0 + Hc[7] * x1 + Hc[8] * x2;
-          }
-          if (p < 3) {  // and the ball columns
-            const float y0 = T.c_Jb[k][0][p], y1 = T.c_Jb[k][1][p], y2 = T.c_Jb[k][2][p];
-            T.c_JBb[k][0][p] = Hc[0] * y0 + Hc[1] * y1 + Hc[2] * y2;
-            T.c_JBb[k][1][p] = Hc[3] * y0 + Hc[4] * y1 + Hc[5] * y2;
-            T.c_JBb[k][2][p] = Hc[6] * y0 + Hc[7] * y1 + Hc[8] * y2;
-          }
-        }
-      }
-      DM_SYNC();
-      BSTAMP(8);  // newton: contact forces / local Hessians
-      // gradient (fly slots + ball), Hessian diagonal additions, coupling columns
-      float g[3], hadd[3], hfb[3][3];
-      float gn2 = 0.f, fn2 = 0.f;
-#pragma unroll
-      for (int s = 0; s < 3; s++) {
-        g[s] = 0.f; hadd[s] = 0.f; lf[s] = 0.f; hfb[s][0] = hfb[s][1] = hfb[s][2] = 0.f;
-        if (slot_on(c, s)) {
-          float gg = Ma[s] - qs[s];
-          if (lsgn[s] != 0.f) {
-            const float r = lsgn[s] * a[s] - laref[s];
-            if (r < 0.f) { lf[s] = -lD[s] * r; gg -= lsgn[s] * lf[s]; hadd[s] = lD[s]; }
-          }
-          if (nc) {
-            gg -= contact_gather(c, opq(c.sbl[s]), T.c_f);
-            const unsigned li = opq(c.sbl[s]) >> 8;
-            unsigned bm = T.c_bmask[opq(c.sbl[s]) & 0xffu];
-            while (bm) {
-              const int k = __ffs(bm) - 1;
-              bm &= bm - 1u;
-              if ((T.c_amask[k] >> li) & 1u) {
-                const int p = __popc(T.c_amask[k] & ((1u << li) - 1u));
-                const float x0 = T.c_J[k][0][p], x1 = T.c_J[k][1][p], x2 = T.c_J[k][2][p];
-#pragma unroll
-                for (int m = 0; m < 3; m++) hfb[s][m] += x0 * T.c_JBb[k][0][m] + x1 * T.c_JBb[k][1][m] + x2 * T.c_JBb[k][2][m];
-              }
-            }
-          }
-          g[s] = gg;
-          gn2 += gg * gg; fn2 += Ma[s] * Ma[s] + qs[s] * qs[s];
-          T.dadd[opq(c.sdof[s])] = hadd[s];
-        }
-      }
-      V3 gb = Ib * ab - qsb;
-      float Hbb[6] = {Ib, 0.f, 0.f, Ib, 0.f, Ib};  // xx xy xz yy yz zz
-      for (int k = 0; k < nc; k++) {
-        const float f0 = T.c_f[k][0], f1 = T.c_f[k][1], f2 = T.c_f[k][2];
-        gb.x -= T.c_Jb[k][0][0] * f0 + T.c_Jb[k][1][0] * f1 + T.c_Jb[k][2][0] * f2;
-        gb.y -= T.c_Jb[k][0][1] * f0 + T.c_Jb[k][1][1] * f1 + T.c_Jb[k][2][1] * f2;
-        gb.z -= T.c_Jb[k][0][2] * f0 + T.c_Jb[k][1][2] * f1 + T.c_Jb[k][2][2] * f2;
-        const float (*J)[3] = T.c_Jb[k];
-        const float (*B)[3] = T.c_JBb[k];
-        Hbb[0] += J[0][0] * B[0][0] + J[1][0] * B[1][0] + J[2][0] * B[2][0];
-        Hbb[1] += J[0][0] * B[0][1] + J[1][0] * B[1][1] + J[2][0] * B[2][1];
-        Hbb[2] += J[0][0] * B[0][2] + J[1][0] * B[1][2] + J[2][0] * B[2][2];
-        Hbb[3] += J[0][1] * B[0][1] + J[1][1] * B[1][1] + J[2][1] * B[2][1];
-        Hbb[4] += J[0][1] * B[0][2] + J[1][1] * B[1][2] + J[2][1] * B[2][2];
-        Hbb[5] += J[0][2] * B[0][2] + J[1][2] * B[1][2] + J[2][2] * B[2][2];
-      }
-      gn2 = wave_sum(gn2) + dot(gb, gb);
-      fn2 = wave_sum(fn2) + dot(qsb, qsb);
-      if ((it > 0 || warm) && gn2 <= kNewtonTol2 * fn2 + 1e-30f) break;
+      yv = y0v + gdot(lam);
+      fv = eval(yv, true);
+      const float ev = lam - fv;
+      const float pv = gdot(ev);
+      const float gn2 = wave_sum(lane < R ? pv * ev : 0.f);
+      if ((it > 0 || c.have_ws) && gn2 <= kNewtonTol2 * scale2 + 1e-30f) break;
       iters++;
-      BSTAMP(9);  // newton: gradient
-      // H_ff = M + diag(limit D) + sum_c J_f' Hc J_f  (same sparsity as M: a contact row only spans one chain)
-      DM_SYNC();
-#pragma unroll 2
-      for (int t = 0; t < ECAP; t++) {
-        const unsigned ea = M.ent_a[t][lane], eb = M.ent_b[t][lane];
-        if (ea >> 31) {
-          const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu, adr = (ea >> 16) & 0x3ffu, blk = eb & 0xfu, lii = (eb >> 4) & 0xfu, lij = (eb >> 8) & 0xfu;
-          float hv = T.Mq[adr];
-          if (i == j) hv += T.dadd[i];
-          unsigned bm = T.c_bmask[blk];
-          while (bm) {
-            const int k = __ffs(bm) - 1;
-            bm &= bm - 1u;
-            const unsigned am_ = T.c_amask[k];
-            if ((am_ >> lii) & 1u) {
-              const int pi = __popc(am_ & ((1u << lii) - 1u)), pj = __popc(am_ & ((1u << lij) - 1u));
-              hv += T.c_J[k][0][pi] * T.c_JB[k][0][pj] + T.c_J[k][1][pi] * T.c_JB[k][1][pj] + T.c_J[k][2][pi] * T.c_JB[k][2][pj];
-            }
-          }
-          T.Lh[adr] = hv;
+      // S = I + L' G L.  Column j: t_j = (G L)[lane][j] from this lane's G row and L's column j (read from the owning lanes),
+      // then S[i][j] = delta_ij + sum over the rows a >= i of i's block of L[a][i] t_j(a) (neighbour lanes, shifted in).
+      const float La1 = __shfl_down(sub == 1 ? L0 : (sub == 2 ? L1 : 0.f), 1);  // L[lane+1][lane] (the source lane picks its entry one column left of its diagonal)
+      const float La2 = __shfl_down(L0, 2);                                      // L[lane+2][lane] (only for sub == 0)
+      const float Ld = sub == 0 ? L0 : (sub == 1 ? L1 : L2);                     // L[lane][lane]
+      const bool has1 = crow && sub < 2, has2 = crow && sub == 0;
+#pragma unroll
+      for (int j = 0; j < RMAX; j++) {
+        if (j < R) {
+        float tj;
+        if (j < nrc) {
+          const int fj = j - j % 3, sj = j % 3;
+          // L[fj + b][j] for b = sj .. 2: lane fj+b holds it at position sj
+          tj = Gr[j] * rl_f(sj == 0 ? L0 : (sj == 1 ? L1 : L2), j);
+          if (sj < 2) tj += Gr[fj + sj + 1 < RMAX ? fj + sj + 1 : 0] * rl_f(sj == 0 ? L0 : L1, fj + sj + 1 < RMAX ? fj + sj + 1 : 0);
+          if (sj < 1) tj += Gr[fj + 2 < RMAX ? fj + 2 : 0] * rl_f(L0, fj + 2 < RMAX ? fj + 2 : 0);
+        } else tj = Gr[j] * rl_f(L0, j);
+        float sij = Ld * tj;
+        const float t1 = __shfl_down(tj, 1), t2 = __shfl_down(tj, 2);
+        if (has1) sij += La1 * t1;
+        if (has2) sij += La2 * t2;
+        Sr[j] = sij + (j == lane ? 1.f : 0.f);
+        } else Sr[j] = j == lane ? 1.f : 0.f;
+      }
+      // rhs = L' p
+      float w = Ld * pv;
+      {
+        const float p1 = __shfl_down(pv, 1), p2 = __shfl_down(pv, 2);
+        if (has1) w += La1 * p1;
+        if (has2) w += La2 * p2;
+      }
+      // Cholesky of S in place (row per lane; the strictly upper part is never read)
+#pragma unroll
+      for (int k = 0; k < RMAX; k++) {
+        if (k < R) {
+          const float ip = __builtin_amdgcn_rsqf(rl_f(Sr[k], k));
+          const float lik = Sr[k] * ip;
+          Sr[k] = lik;
+#pragma unroll
+          for (int j = k + 1; j < RMAX; j++) Sr[j] -= lik * rl_f(lik, j);  // rows / columns beyond R are identity: no-ops
         }
       }
-      DM_SYNC();
-      BSTAMP(10);  // newton: H assembly
-      factor(c, T.Lh, false, T.Lh, T.dinv_h);
-      BSTAMP(11);  // newton: factor
-      // [ -g_f | H_fb ] through H_ff^-1, then the 3x3 Schur complement on the ball
+      const float idg = 1.f / [&]() { float dgv = 1.f;
 #pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(-g[s], hfb[s][0], hfb[s][1], hfb[s][2]);
-      DM_SYNC();
-      solve4(c, T.Lh, T.dinv_h);
-      BSTAMP(12);  // newton: solve
-      float4 xs[3];
-      float sc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // S reductions: xx xy xz yy yz zz, rhs x y z
+        for (int j = 0; j < RMAX; j++) if (j == lane) dgv = Sr[j];
+        return dgv; }();
+      // forward substitution L_s w' = w
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
-        xs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (slot_on(c, s)) {
-          xs[s] = T.X4[opq(c.sdof[s])];
-          sc[0] += hfb[s][0] * xs[s].y; sc[1] += hfb[s][0] * xs[s].z; sc[2] += hfb[s][0] * xs[s].w;
-          sc[3] += hfb[s][1] * xs[s].z; sc[4] += hfb[s][1] * xs[s].w; sc[5] += hfb[s][2] * xs[s].w;
-          sc[6] += hfb[s][0] * xs[s].x; sc[7] += hfb[s][1] * xs[s].x; sc[8] += hfb[s][2] * xs[s].x;
+      for (int k = 0; k < RMAX; k++) {
+        if (k < R) {
+          const float wk = rl_f(w, k) * rl_f(idg, k);
+          w = lane == k ? wk : (lane > k ? w - Sr[k] * wk : w);
         }
       }
-      V3 db;
-      if (nc) {
+      // transpose through LDS (this lane's column of L_s), then backward substitution L_s' u = w'
+      if (lane < R) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) sc[k] = wave_sum(sc[k]);
-        const float S00 = Hbb[0] - sc[0], S01 = Hbb[1] - sc[1], S02 = Hbb[2] - sc[2], S11 = Hbb[3] - sc[3], S12 = Hbb[4] - sc[4], S22 = Hbb[5] - sc[5];
-        const float r0 = -gb.x - sc[6], r1 = -gb.y - sc[7], r2 = -gb.z - sc[8];
-        // 3x3 symmetric solve (Cholesky)
-        const float l00 = sqrtf(S00), l10 = S01 / l00, l20 = S02 / l00, l11 = sqrtf(S11 - l10 * l10), l21 = (S12 - l20 * l10) / l11,
-                    l22 = sqrtf(S22 - l20 * l20 - l21 * l21);
-        const float y0 = r0 / l00, y1 = (r1 - l10 * y0) / l11, y2 = (r2 - l20 * y0 - l21 * y1) / l22;
-        db.z = y2 / l22; db.y = (y1 - l21 * db.z) / l11; db.x = (y0 - l10 * db.y - l20 * db.z) / l00;
-      } else db = (-1.f / Ib) * gb;
-      float dd[3];
-#pragma unroll
-      for (int s = 0; s < 3; s++) dd[s] = xs[s].x - xs[s].y * db.x - xs[s].z * db.y - xs[s].w * db.z;
-      // jd = J d per row; Md = -g - (H - M) d
-#pragma unroll
-      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = dd[s];
-      DM_SYNC();
-      for (int base = 0; base < nc; base += 4) {
-        const int k = base + (lane >> 4), p = lane & 15;
-        const bool on = k < nc;
-        const bool pv = on && p < T.c_nch[k];
-        const float dv = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
-        float jd[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) jd[r] = row_sum(pv ? T.c_J[k][r][p] * dv : 0.f);
-        if (on && p == 0) {
-#pragma unroll
-          for (int r = 0; r < 3; r++) jd[r] += T.c_Jb[k][r][0] * db.x + T.c_Jb[k][r][1] * db.y + T.c_Jb[k][r][2] * db.z;
-          const float *Hc = T.c_Hc[k];
-          T.c_jd[k][0] = jd[0]; T.c_jd[k][1] = jd[1]; T.c_jd[k][2] = jd[2];
-          T.c_w[k][0] = Hc[0] * jd[0] + Hc[1] * jd[1] + Hc[2] * jd[2];
-          T.c_w[k][1] = Hc[3] * jd[0] + Hc[4] * jd[1] + Hc[5] * jd[2];
-          T.c_w[k][2] = Hc[6] * jd[0] + Hc[7] * jd[1] + Hc[8] * jd[2];
-        }
+        for (int j = 0; j < RMAX; j++) if (j < R) T.S[lane][j] = Sr[j];
       }
       DM_SYNC();
-      float Md[3], c0s = 0.f, c1s = 0.f;
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
-        Md[s] = 0.f;
-        if (slot_on(c, s)) {
-          float md = -g[s] - hadd[s] * dd[s];
-          if (nc) md -= contact_gather(c, opq(c.sbl[s]), T.c_w);
-          Md[s] = md;
-          c0s += (Ma[s] - qs[s]) * dd[s]; c1s += md * dd[s];
+      for (int k = 0; k < RMAX; k++) Sr[k] = (lane < R && k < R && k >= lane) ? T.S[k][lane] : 0.f;
+      DM_SYNC();
+#pragma unroll
+      for (int k = RMAX - 1; k >= 0; k--) {
+        if (k < R) {
+          const float uk = rl_f(w, k) * rl_f(idg, k);
+          w = lane == k ? uk : (lane < k ? w - Sr[k] * uk : w);
         }
       }
-      c0s = wave_sum(c0s) + dot(Ib * ab - qsb, db);
-      c1s = wave_sum(c1s) + Ib * dot(db, db);
-      BSTAMP(13);  // newton: Schur, jd, Md
-      // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(jar + alpha jd) jd
+      // d = -e + L u, jd = G d
+      float dl = -ev + Ld * w;
+      {
+        const float u1 = __shfl_up(w, 1), u2 = __shfl_up(w, 2);
+        if (crow && sub >= 1) dl += (sub == 1 ? L0 : L1) * u1;
+        if (crow && sub == 2) dl += L0 * u2;
+      }
+      if (lane >= R) dl = 0.f;
+      const float jdv = gdot(dl);
+      const float c0s = wave_sum(lane < R ? lam * jdv : 0.f), c1s = wave_sum(lane < R ? dl * jdv : 0.f);
+      BSTAMP(9);  // newton: rows, S, Cholesky, direction
+      // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(y + alpha jd) jd
       auto dphi = [&](float al) {
-        float acc = 0.f;
-#pragma unroll
-        for (int s = 0; s < 3; s++) {
-          if (lsgn[s] != 0.f) {
-            const float jdv = lsgn[s] * dd[s], r = lsgn[s] * a[s] - laref[s] + al * jdv;
-            if (r < 0.f) acc += lD[s] * r * jdv;
-          }
-        }
-        if (lane < nc && !T.c_excl[lane]) {
-          float f0, f1, f2;
-          const float *jr = T.c_jar[lane], *jd = T.c_jd[lane];
-          cone_force(T.c_D[lane], T.c_mu[lane], jr[0] + al * jd[0], jr[1] + al * jd[1], jr[2] + al * jd[2], f0, f1, f2, nullptr);
-          acc -= f0 * jd[0] + f1 * jd[1] + f2 * jd[2];
-        }
+        const float fa = eval(yv + al * jdv, false);
+        float acc = lane < R ? -fa * jdv : 0.f;
         return c0s + al * c1s + wave_sum(acc);
       };
       float alpha = 0.f;
@@ -944,8 +971,6 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         else {
 #pragma unroll 1
           for (int ls = 0; ls < kLsIter; ls++) {
-            if (fabsf(dhi) <= kLsTol * fabsf(d0)) { lo = hi; dlo = dhi; break; }
-            // regula falsi step safeguarded by bisection
             float mid = lo - dlo * (hi - lo) / (dhi - dlo);
             if (!(mid > lo + 0.05f * (hi - lo)) || !(mid < hi - 0.05f * (hi - lo))) mid = 0.5f * (lo + hi);
             const float dm_ = dphi(mid);
@@ -956,125 +981,33 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           if (!(alpha >= lo) || !(alpha <= hi)) alpha = 0.5f * (lo + hi);
         }
       }
-#pragma unroll
-      for (int s = 0; s < 3; s++) { a[s] += alpha * dd[s]; Ma[s] += alpha * Md[s]; }
-      ab = ab + alpha * db;
+      lam += alpha * dl;
       BSTAMP(14);  // newton: line search
     }
-    // final forces at the solution
-#pragma unroll
-    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = a[s];
-    DM_SYNC();
-    for (int base = 0; base < nc; base += 4) {
-      const int k = base + (lane >> 4), p = lane & 15;
-      const bool on = k < nc;
-      const bool pv = on && p < T.c_nch[k];
-      const float av = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
-      float jar[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) jar[r] = row_sum(pv ? T.c_J[k][r][p] * av : 0.f);
-      if (on && p == 0) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) jar[r] += T.c_Jb[k][r][0] * ab.x + T.c_Jb[k][r][1] * ab.y + T.c_Jb[k][r][2] * ab.z - T.c_aref[k][r];
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-        if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], jar[0], jar[1], jar[2], f0, f1, f2, nullptr);
-        T.c_f[k][0] = f0; T.c_f[k][1] = f1; T.c_f[k][2] = f2;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-      lf[s] = 0.f;
-      if (lsgn[s] != 0.f) { const float r = lsgn[s] * a[s] - laref[s]; if (r < 0.f) lf[s] = -lD[s] * r; }
-    }
-    DM_SYNC();
-  } else {
-    for (int k = lane; k < nc * 3; k += 64) T.c_f[k / 3][k % 3] = 0.f;
+    // forces at the solution
+    yv = y0v + gdot(lam);
+    fv = eval(yv, false);
+    if (lane < R) { T.r_lam[lane] = lam; T.r_y[lane] = yv; T.r_f[lane] = fv; }
     DM_SYNC();
   }
   iters_out += iters;
   BSTAMP(15);  // newton: final forces
   // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
-  //      unregularised A = J M^-1 J'; everything else (normal and limit forces) enters through w0 = M^-1 J' f_other
-  bool did_noslip = false;
+  //      unregularised A = J M^-1 J' - which is G - normal and limit forces held fixed; res = G f + (J a_s - aref)
+  int nact = 0;
+  for (int k = 0; k < nc; k++) nact += T.c_excl[k] ? 0 : 1;
   if (nact > 0 && M.noslip_iterations > 0 && !(c.flags & BF_NO_NOSLIP)) {
-    did_noslip = true;
-    const int nr = 2 * nc;
-    // right-hand sides through M^-1 four at a time: column 0 of the first batch is J' f_other (-> w0), the rest are the
-    // tangential rows J_t' (-> the columns of A_tt, written straight into the idle link-exchange buffer)
-    for (int k = lane; k < nc; k += 64) { T.c_w[k][0] = T.c_f[k][0]; T.c_w[k][1] = 0.f; T.c_w[k][2] = 0.f; }
-    DM_SYNC();
-    float w0rhs[3];
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-      w0rhs[s] = 0.f;
-      if (slot_on(c, s)) { w0rhs[s] = lsgn[s] * lf[s] + contact_gather(c, opq(c.sbl[s]), T.c_w); T.dadd[opq(c.sdof[s])] = am[s]; }
-    }
-    V3 w0b = {0.f, 0.f, 0.f};
-    for (int k = 0; k < nc; k++) {
-      w0b.x += T.c_Jb[k][0][0] * T.c_f[k][0]; w0b.y += T.c_Jb[k][0][1] * T.c_f[k][0]; w0b.z += T.c_Jb[k][0][2] * T.c_f[k][0];
-    }
-    w0b = (1.f / Ib) * w0b;
-    float brow = 0.f;
-#pragma unroll 1
-    for (int base = -1; base < nr; base += 4) {  // columns base .. base + 3 (column -1 = w0)
-      for (int f = lane; f < ND; f += 64) T.X4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-      DM_SYNC();
-      if (base < 0) {
-#pragma unroll
-        for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = w0rhs[s];
-      }
-      for (int item = lane; item < 4 * NCH; item += 64) {
-        const int col = item / NCH, p = item - col * NCH, row = base + col;
-        if (row >= 0 && row < nr) {
-          const int k = row >> 1, r = 1 + (row & 1);
-          if (p < T.c_nch[k]) (&T.X4[T.c_chain[k][p]].x)[col] = T.c_J[k][r][p];
-        }
-      }
-      DM_SYNC();
-      solve4(c, T.Lm, T.dinv_m);
-      if (lane < nr) {
-        const int k = lane >> 1, r = 1 + (lane & 1), nch = T.c_nch[k];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float accs = 0.f;
-        for (int p = 0; p < nch; p++) {
-          const float jv = T.c_J[k][r][p];
-          const int f = T.c_chain[k][p];
-          const float4 y = T.X4[f];
-          acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
-          if (base < 0) accs += jv * T.dadd[f];
-        }
-        if (base < 0) {  // b' = J_t (a_smooth + w0) - aref_t
-          const V3 ub = amb + w0b;
-          brow = accs + acc.x - T.c_aref[k][r] + T.c_Jb[k][r][0] * ub.x + T.c_Jb[k][r][1] * ub.y + T.c_Jb[k][r][2] * ub.z;
-        }
-#pragma unroll
-        for (int col = 0; col < 4; col++) {
-          const int row = base + col;
-          if (row >= 0 && row < nr) {
-            const int k2 = row >> 1, r2 = 1 + (row & 1);
-            const float ball = (T.c_Jb[k][r][0] * T.c_Jb[k2][r2][0] + T.c_Jb[k][r][1] * T.c_Jb[k2][r2][1] + T.c_Jb[k][r][2] * T.c_Jb[k2][r2][2]) / Ib;
-            T.ns.A[lane][row] = (col == 0 ? acc.x : (col == 1 ? acc.y : (col == 2 ? acc.z : acc.w))) + ball;
-          }
-        }
-      }
-      DM_SYNC();
-    }
-    if (lane < nr) {
-      T.ns.b[lane] = brow;
-      T.ns.f[lane] = T.c_f[lane >> 1][1 + (lane & 1)];
-    }
-    DM_SYNC();
     const float scale = 1.f / (M.meaninertia * 105.f);
     for (int iter = 0; iter < M.noslip_iterations; iter++) {
       float improvement = 0.f;
       for (int k = 0; k < nc; k++) {
         if (T.c_excl[k]) continue;
-        const int r0 = 2 * k, r1 = 2 * k + 1;
-        float res0 = T.ns.b[r0], res1 = T.ns.b[r1];
-        for (int q2 = 0; q2 < nr; q2++) { const float fv = T.ns.f[q2]; res0 += T.ns.A[r0][q2] * fv; res1 += T.ns.A[r1][q2] * fv; }
-        const float o0 = T.ns.f[r0], o1 = T.ns.f[r1];
-        const float A00 = T.ns.A[r0][r0], A01 = T.ns.A[r0][r1], A11 = T.ns.A[r1][r1];
-        const float fn = T.c_f[k][0];
+        const int r0 = 3 * k + 1, r1 = 3 * k + 2;
+        float res0 = T.r_y0[r0], res1 = T.r_y0[r1];
+        for (int q2 = 0; q2 < R; q2++) { const float fv = T.r_f[q2]; res0 += T.G[r0][q2] * fv; res1 += T.G[r1][q2] * fv; }
+        const float o0 = T.r_f[r0], o1 = T.r_f[r1];
+        const float A00 = T.G[r0][r0], A01 = T.G[r0][r1], A11 = T.G[r1][r1];
+        const float fn = T.r_f[3 * k];
         float v0 = 0.f, v1 = 0.f;
         if (fn >= 1e-15f) {
           const float b0 = res0 - A00 * o0 - A01 * o1, b1 = res1 - A01 * o0 - A11 * o1, mu = T.c_mu[k];
@@ -1094,25 +1027,27 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         change = fminf(change, 0.f);
         improvement -= change;
         DM_SYNC();
-        if (lane == 0) { T.ns.f[r0] = v0; T.ns.f[r1] = v1; }
+        if (lane == 0) { T.r_f[r0] = v0; T.r_f[r1] = v1; }
         DM_SYNC();
       }
       if (improvement * scale < 1e-6f) break;
     }
-    if (lane < nr) T.c_f[lane >> 1][1 + (lane & 1)] = T.ns.f[lane];
-    DM_SYNC();
   }
   BSTAMP(16);  // noslip
-  // ---- constraint forces in joint space, final acceleration
-  float qc[3];
+  // ---- constraint forces in joint space, final acceleration a = a_s + M^-1 J' f
+  if (lane < nrc) T.c_f[lane / 3][lane % 3] = constrained ? T.r_f[lane] : 0.f;
+  DM_SYNC();
+  float qc[3], a[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
     qc[s] = 0.f;
     if (slot_on(c, s)) {
-      qc[s] = lsgn[s] * lf[s];
+      if (lrow[s] >= 0) { const float lf_ = T.r_f[lrow[s]]; qc[s] = lsgn[s] * lf_; c.wsl[s] = lf_; } else c.wsl[s] = 0.f;
       if (nc) qc[s] += contact_gather(c, opq(c.sbl[s]), T.c_f);
     }
   }
+  c.wsc[0] = c.wsc[1] = c.wsc[2] = 0.f;
+  for (int k = 0; k < nc; k++) if (T.c_link[k] == lane) { c.wsc[0] = T.c_f[k][0]; c.wsc[1] = T.c_f[k][1]; c.wsc[2] = T.c_f[k][2]; }
   V3 qcb = {0.f, 0.f, 0.f};
   for (int k = 0; k < nc; k++) {
     const float f0 = T.c_f[k][0], f1 = T.c_f[k][1], f2 = T.c_f[k][2];
@@ -1120,7 +1055,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     qcb.y += T.c_Jb[k][0][1] * f0 + T.c_Jb[k][1][1] * f1 + T.c_Jb[k][2][1] * f2;
     qcb.z += T.c_Jb[k][0][2] * f0 + T.c_Jb[k][1][2] * f1 + T.c_Jb[k][2][2] * f2;
   }
-  if (did_noslip) {  // qacc = a_s + M^-1 J' f with the swept forces
+  V3 ab = amb;
+  if (constrained) {
 #pragma unroll
     for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(qc[s], 0.f, 0.f, 0.f);
     DM_SYNC();
@@ -1129,15 +1065,15 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     for (int s = 0; s < 3; s++) a[s] = slot_on(c, s) ? am[s] + T.X4[opq(c.sdof[s])].x : 0.f;
     ab = amb + (1.f / Ib) * qcb;
     DM_SYNC();
+  } else {
+#pragma unroll
+    for (int s = 0; s < 3; s++) a[s] = am[s];
   }
   {
     float n2 = 0.f;
 #pragma unroll
     for (int s = 0; s < 3; s++) if (slot_on(c, s)) n2 += a[s] * a[s];
     *qacc_norm2 = wave_sum(n2) + dot(ab, ab);
-#pragma unroll
-    for (int s = 0; s < 3; s++) c.aws[s] = a[s];
-    c.abws = ab;
     c.have_ws = 1;
   }
   BSTAMP(17);  // constraint forces, final acceleration
@@ -1270,17 +1206,17 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     for (int s = 0; s < 3; s++)
       if (slot_on(c, s)) for (int w = 0; w < M.nwing; w++) if (M.wing_dof[w] == c.sdof[s]) c.q[s] = M.qspring[c.sdof[s]];
     c.bq = {1.f, 0.f, 0.f, 0.f}; c.bw = {0.f, 0.f, 0.f};
-    c.have_ws = 0; c.abws = {0.f, 0.f, 0.f};
+    c.have_ws = 0;
 #pragma unroll
-    for (int s = 0; s < 3; s++) c.aws[s] = 0.f;
+    for (int s = 0; s < 3; s++) { c.wsl[s] = 0.f; c.wsc[s] = 0.f; }
     step_counter = 0;
   } else {
 #pragma unroll
     for (int s = 0; s < 3; s++) { c.q[s] = slot_on(c, s) ? S.q[c.sdof[s]] : 0.f; c.v[s] = slot_on(c, s) ? S.v[c.sdof[s]] : 0.f; }
     c.bq = {S.ballq[0], S.ballq[1], S.ballq[2], S.ballq[3]}; c.bw = {S.ballw[0], S.ballw[1], S.ballw[2]};
-    c.have_ws = S.have_ws; c.abws = {S.ballacc_ws[0], S.ballacc_ws[1], S.ballacc_ws[2]};
+    c.have_ws = S.have_ws;
 #pragma unroll
-    for (int s = 0; s < 3; s++) c.aws[s] = slot_on(c, s) ? S.qacc_ws[c.sdof[s]] : 0.f;
+    for (int s = 0; s < 3; s++) { c.wsl[s] = slot_on(c, s) ? S.qacc_ws[c.sdof[s]] : 0.f; c.wsc[s] = S.wsc[lane][s]; }
     act_reg = lane < NU ? S.act[lane] : 0.f;
     if (lane < NU) {
       if (phys_only) ctrl_reg = act[(size_t)env * NU + lane];
@@ -1317,14 +1253,16 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   c.flags = K.flags;
   // ---- store state
 #pragma unroll
-  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { S.q[c.sdof[s]] = c.q[s]; S.v[c.sdof[s]] = c.v[s]; S.qacc_ws[c.sdof[s]] = c.aws[s]; }
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) { S.q[c.sdof[s]] = c.q[s]; S.v[c.sdof[s]] = c.v[s]; S.qacc_ws[c.sdof[s]] = c.wsl[s]; }
+#pragma unroll
+  for (int s = 0; s < 3; s++) S.wsc[lane][s] = c.wsc[s];
   if (lane < NU) S.act[lane] = do_reset ? 0.f : act_reg;
   if (lane == 0) {
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
     S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc;
     if (do_reset) S.overflow = 0; else if (c.overflow) S.overflow = 1;
-    S.have_ws = do_reset ? 0 : c.have_ws; S.ballacc_ws[0] = c.abws.x; S.ballacc_ws[1] = c.abws.y; S.ballacc_ws[2] = c.abws.z;
+    S.have_ws = do_reset ? 0 : c.have_ws;
   }
 #ifdef FFB_STAMPS
   BSTAMP(20);  // prologue + state store

@@ -37,7 +37,8 @@ constexpr int NMMAX = 584;  // M entries (580) padded
 constexpr int ECAP = 10;    // M entries per lane
 constexpr int NSTEP = 14;   // pivots per block (largest block: abdomen / head tree, 14 dofs)
 constexpr int NBLK = 12;    // independent blocks of M (6 legs, head tree, abdomen, 2 wings, 2 halteres)
-constexpr int NC = 12;      // contact capacity per env (oracle rollouts peak at 9; overflow is flagged)
+constexpr int NC = 10;      // contact capacity per env (oracle rollouts peak at 9; overflow is flagged)
+constexpr int RMAX = 32;    // constraint rows per env: 3 per contact + instantiated joint limits (peak seen 26; overflow is flagged)
 constexpr int NCH = 14;     // fly dofs a contact row can touch (deepest chain)
 constexpr int NU = 59;      // actuators
 constexpr int NWRAP = 7;    // transmission terms per actuator

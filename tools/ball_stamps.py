@@ -12,8 +12,8 @@ import torch
 from flybody_amd import _capi, fly_envs
 
 NAMES = ["kinematics sweep", "velocity sweep", "body forces + subtree sweep", "joint forces + M assembly", "factor M", "collision",
-         "actuation + contact rows", "smooth solve", "newton: contact forces", "newton: gradient", "newton: H assembly", "newton: factor",
-         "newton: solve", "newton: Schur/jd/Md", "newton: line search", "newton: final forces", "noslip", "constraint forces", "sensors",
+         "actuation + contact rows", "smooth solve", "rows + G (block solves)", "newton: rows, S, Cholesky, direction", "-", "-",
+         "-", "-", "newton: line search", "newton: final forces", "noslip", "constraint forces + final solve", "sensors",
          "Euler", "prologue + store"]
 B = 4096
 env = fly_envs.walk_on_ball(batch_size=B)
