@@ -567,6 +567,222 @@ __device__ __forceinline__ bool qcqp2(float &x0, float &x1, float A00, float A01
   return active;
 }
 
+// Dense Newton of the constraint solve on R <= RB rows (RB = 16 / 24 / 32 picked per substep): lane = row, everything in
+// registers - the lane's row of G and of S = I + L' G L, other lanes' scalars by v_readlane (uniform index), neighbours'
+// by bpermute shifts.  Loops are fully unrolled over RB so that the register arrays keep static indices.
+template <int RB>
+__device__ __forceinline__ int dense_newton(Ctx &c, const int R, const int nrc, const float scale2, const int nslip) {
+  BTile &T = *c.T;
+  const int lane = c.lane;
+  int iters = 0;
+    float Gr[RB], Sr[RB];
+#pragma unroll
+    for (int j = 0; j < RB; j++) Gr[j] = (lane < R && j < R) ? T.G[lane][j] : 0.f;
+    float lam = lane < R ? T.r_lam[lane] : 0.f;
+    const float y0v = lane < R ? T.r_y0[lane] : 0.f;
+    const bool crow = lane < nrc;           // contact row (else limit row or idle lane)
+    const int sub = crow ? lane % 3 : 0;    // position inside the contact's 3-row block
+    auto gdot = [&](float vreg) {           // (G v)[lane], v given as one value per lane
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < RB; j++) acc += Gr[j] * rl_f(vreg, j);  // Gr[j] = 0 beyond the R live rows
+      return acc;
+    };
+    float fv = 0.f, yv = 0.f;
+    float L0 = 0.f, L1 = 0.f, L2 = 0.f;  // this row of the block-lower Cholesky factor of W: L[row][first .. first+2]
+    auto eval = [&](float y, bool want_L) {
+      // a contact's three rows are evaluated on all three lanes (the residuals come by shifts inside the block)
+      const float ya = __shfl(y, lane - sub), yb = __shfl(y, lane - sub + 1), yc = __shfl(y, lane - sub + 2);
+      float f = 0.f;
+      if (want_L) L0 = L1 = L2 = 0.f;
+      if (crow) {
+        const int k = lane / 3;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, Hc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], ya, yb, yc, f0, f1, f2, want_L ? Hc : nullptr);
+        f = sub == 0 ? f0 : (sub == 1 ? f1 : f2);
+        if (want_L) {  // Hc = L L' (positive semi-definite: a vanishing pivot zeroes its column)
+          const float l00 = Hc[0] > 1e-30f ? sqrtf(Hc[0]) : 0.f, i00 = l00 > 0.f ? 1.f / l00 : 0.f;
+          const float l10 = Hc[3] * i00, l20 = Hc[6] * i00;
+          const float d1 = Hc[4] - l10 * l10, l11 = d1 > 1e-7f * Hc[4] ? sqrtf(d1) : 0.f, i11 = l11 > 0.f ? 1.f / l11 : 0.f;
+          const float l21 = (Hc[7] - l20 * l10) * i11;
+          const float d2 = Hc[8] - l20 * l20 - l21 * l21, l22 = d2 > 1e-7f * Hc[8] ? sqrtf(d2) : 0.f;
+          if (sub == 0) { L0 = l00; } else if (sub == 1) { L0 = l10; L1 = l11; } else { L0 = l20; L1 = l21; L2 = l22; }
+        }
+      } else if (lane < R) {
+        const float D = T.r_D[lane];
+        f = y < 0.f ? -D * y : 0.f;
+        if (want_L) L0 = y < 0.f ? sqrtf(D) : 0.f;
+      }
+      return f;
+    };
+#pragma unroll 1
+    for (int it = 0; it < kMaxNewton; it++) {
+      yv = y0v + gdot(lam);
+      fv = eval(yv, true);
+      const float ev = lam - fv;
+      const float pv = gdot(ev);
+      const float gn2 = wave_sum(lane < R ? pv * ev : 0.f);
+      if ((it > 0 || c.have_ws) && gn2 <= kNewtonTol2 * scale2 + 1e-30f) break;
+      iters++;
+      // S = I + L' G L.  Column j: t_j = (G L)[lane][j] from this lane's G row and L's column j (read from the owning lanes),
+      // then S[i][j] = delta_ij + sum over the rows a >= i of i's block of L[a][i] t_j(a) (neighbour lanes, shifted in).
+      const float La1 = __shfl_down(sub == 1 ? L0 : (sub == 2 ? L1 : 0.f), 1);  // L[lane+1][lane] (the source lane picks its entry one column left of its diagonal)
+      const float La2 = __shfl_down(L0, 2);                                      // L[lane+2][lane] (only for sub == 0)
+      const float Ld = sub == 0 ? L0 : (sub == 1 ? L1 : L2);                     // L[lane][lane]
+      const bool has1 = crow && sub < 2, has2 = crow && sub == 0;
+#pragma unroll
+      for (int j = 0; j < RB; j++) {
+        if (j < R) {
+        float tj;
+        if (j < nrc) {
+          const int fj = j - j % 3, sj = j % 3;
+          // L[fj + b][j] for b = sj .. 2: lane fj+b holds it at position sj
+          tj = Gr[j] * rl_f(sj == 0 ? L0 : (sj == 1 ? L1 : L2), j);
+          if (sj < 2) tj += Gr[fj + sj + 1 < RB ? fj + sj + 1 : 0] * rl_f(sj == 0 ? L0 : L1, fj + sj + 1 < RB ? fj + sj + 1 : 0);
+          if (sj < 1) tj += Gr[fj + 2 < RB ? fj + 2 : 0] * rl_f(L0, fj + 2 < RB ? fj + 2 : 0);
+        } else tj = Gr[j] * rl_f(L0, j);
+        float sij = Ld * tj;
+        const float t1 = __shfl_down(tj, 1), t2 = __shfl_down(tj, 2);
+        if (has1) sij += La1 * t1;
+        if (has2) sij += La2 * t2;
+        Sr[j] = sij + (j == lane ? 1.f : 0.f);
+        } else Sr[j] = j == lane ? 1.f : 0.f;
+      }
+      // rhs = L' p
+      float w = Ld * pv;
+      {
+        const float p1 = __shfl_down(pv, 1), p2 = __shfl_down(pv, 2);
+        if (has1) w += La1 * p1;
+        if (has2) w += La2 * p2;
+      }
+      // Cholesky of S in place (row per lane; the strictly upper part is never read)
+#pragma unroll
+      for (int k = 0; k < RB; k++) {
+        if (k < R) {
+          const float ip = __builtin_amdgcn_rsqf(rl_f(Sr[k], k));
+          const float lik = Sr[k] * ip;
+          Sr[k] = lik;
+#pragma unroll
+          for (int j = k + 1; j < RB; j++) Sr[j] -= lik * rl_f(lik, j);  // rows / columns beyond R are identity: no-ops
+        }
+      }
+      const float idg = 1.f / [&]() { float dgv = 1.f;
+#pragma unroll
+        for (int j = 0; j < RB; j++) if (j == lane) dgv = Sr[j];
+        return dgv; }();
+      // forward substitution L_s w' = w
+#pragma unroll
+      for (int k = 0; k < RB; k++) {
+        if (k < R) {
+          const float wk = rl_f(w, k) * rl_f(idg, k);
+          w = lane == k ? wk : (lane > k ? w - Sr[k] * wk : w);
+        }
+      }
+      // transpose through LDS (this lane's column of L_s), then backward substitution L_s' u = w'
+      if (lane < R) {
+#pragma unroll
+        for (int j = 0; j < RB; j++) if (j < R) T.S[lane][j] = Sr[j];
+      }
+      DM_SYNC();
+#pragma unroll
+      for (int k = 0; k < RB; k++) Sr[k] = (lane < R && k < R && k >= lane) ? T.S[k][lane] : 0.f;
+      DM_SYNC();
+#pragma unroll
+      for (int k = RB - 1; k >= 0; k--) {
+        if (k < R) {
+          const float uk = rl_f(w, k) * rl_f(idg, k);
+          w = lane == k ? uk : (lane < k ? w - Sr[k] * uk : w);
+        }
+      }
+      // d = -e + L u, jd = G d
+      float dl = -ev + Ld * w;
+      {
+        const float u1 = __shfl_up(w, 1), u2 = __shfl_up(w, 2);
+        if (crow && sub >= 1) dl += (sub == 1 ? L0 : L1) * u1;
+        if (crow && sub == 2) dl += L0 * u2;
+      }
+      if (lane >= R) dl = 0.f;
+      const float jdv = gdot(dl);
+      const float c0s = wave_sum(lane < R ? lam * jdv : 0.f), c1s = wave_sum(lane < R ? dl * jdv : 0.f);
+      BSTAMP(9);  // newton: rows, S, Cholesky, direction
+      // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(y + alpha jd) jd
+      auto dphi = [&](float al) {
+        const float fa = eval(yv + al * jdv, false);
+        float acc = lane < R ? -fa * jdv : 0.f;
+        return c0s + al * c1s + wave_sum(acc);
+      };
+      float alpha = 0.f;
+      {
+        const float d0 = c0s - wave_sum(lane < R ? fv * jdv : 0.f);  // phi'(0): the forces at y are already known
+        if (!(d0 < 0.f)) break;  // not a descent direction any more: converged to rounding
+        float lo = 0.f, hi = 1.f, dlo = d0, dhi = dphi(1.f);
+        int guard = 0;
+        while (dhi < 0.f && fabsf(dhi) > kLsTol * fabsf(d0) && guard++ < 8) { lo = hi; dlo = dhi; hi *= 2.f; dhi = dphi(hi); }
+        if (dhi < 0.f || fabsf(dhi) <= kLsTol * fabsf(d0)) alpha = hi;  // full (or doubled) Newton step: |phi'| already small
+        else {
+#pragma unroll 1
+          for (int ls = 0; ls < kLsIter; ls++) {
+            float mid = lo - dlo * (hi - lo) / (dhi - dlo);
+            if (!(mid > lo + 0.05f * (hi - lo)) || !(mid < hi - 0.05f * (hi - lo))) mid = 0.5f * (lo + hi);
+            const float dm_ = dphi(mid);
+            if (dm_ < 0.f) { lo = mid; dlo = dm_; } else { hi = mid; dhi = dm_; }
+            if (fabsf(dm_) <= kLsTol * fabsf(d0) || hi - lo <= 1e-6f * hi) break;
+          }
+          alpha = (dhi - dlo) != 0.f ? lo - dlo * (hi - lo) / (dhi - dlo) : hi;
+          if (!(alpha >= lo) || !(alpha <= hi)) alpha = 0.5f * (lo + hi);
+        }
+      }
+      lam += alpha * dl;
+      BSTAMP(14);  // newton: line search
+    }
+    // forces at the solution
+    yv = y0v + gdot(lam);
+    fv = eval(yv, false);
+    BSTAMP(15);  // newton: final forces
+    // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
+    //      unregularised A = J M^-1 J' - which is G - normal and limit forces held fixed; res = G f + (J a_s - aref).
+    //      G is symmetric, so row r of G against f is a wave sum over the lanes' column-r entries.
+    if (nslip > 0) {
+      const BallModel FFE_GLOBAL &M = model(c);
+      const float scale = 1.f / (M.meaninertia * 105.f);
+      const int nc = nrc / 3;
+      for (int iter = 0; iter < nslip; iter++) {
+        float improvement = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+          if (3 * k + 2 < RB && k < nc && !T.c_excl[k]) {
+            const int r0 = 3 * k + 1, r1 = 3 * k + 2;
+            const float res0 = rl_f(y0v, r0) + wave_sum(Gr[r0] * fv), res1 = rl_f(y0v, r1) + wave_sum(Gr[r1] * fv);
+            const float o0 = rl_f(fv, r0), o1 = rl_f(fv, r1), fn = rl_f(fv, 3 * k);
+            const float A00 = rl_f(Gr[r0], r0), A01 = rl_f(Gr[r1], r0), A11 = rl_f(Gr[r1], r1);
+            float v0 = 0.f, v1 = 0.f;
+            if (fn >= 1e-15f) {
+              const float b0 = res0 - A00 * o0 - A01 * o1, b1 = res1 - A01 * o0 - A11 * o1, mu = T.c_mu[k];
+              const bool active = qcqp2(v0, v1, A00, A01, A11, b0, b1, mu, fn);
+              if (active) {
+                const float ssum = (v0 * v0 + v1 * v1) / (mu * mu);
+                const float sc2 = sqrtf(fn * fn / fmaxf(1e-15f, ssum));
+                v0 *= sc2; v1 *= sc2;
+              }
+            }
+            const float d0 = v0 - o0, d1 = v1 - o1;
+            // mj: costChange reverts an update whose cost change is > 1e-10 (a failed QCQP).  In float32 the two terms below
+            // cancel to ~1e-7 of their size, so the threshold is taken relative to them; a genuine failure is far above it.
+            const float lin_ = d0 * res0 + d1 * res1, quad_ = 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1));
+            float change = lin_ + quad_;
+            if (change > 1e-10f + 1e-4f * (fabsf(lin_) + fabsf(quad_))) { v0 = o0; v1 = o1; change = 0.f; }
+            improvement -= fminf(change, 0.f);
+            fv = lane == r0 ? v0 : (lane == r1 ? v1 : fv);
+          }
+        }
+        if (improvement * scale < 1e-6f) break;
+      }
+    }
+    if (lane < R) { T.r_lam[lane] = lam; T.r_y[lane] = yv; T.r_f[lane] = fv; }
+    DM_SYNC();
+  return iters;
+}
+
 // ------------------------------------------------------------------------------------------------ stage 2
 __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, float &act_out, bool integrate, int &iters_out, float *qacc_norm2) {
   BTile &T = *c.T;
@@ -821,218 +1037,14 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     for (int s = 0; s < 3; s++) if (slot_on(c, s)) sq += qs[s] * am[s];
     return wave_sum(sq) + dot(qsb, amb); }();
   if (constrained) {
-    // Dense Newton on <= 32 rows, lane = row, everything in registers: the lane's row of G and of S = I + L' G L, other
-    // lanes' scalars by v_readlane (uniform index), neighbours' by DPP / bpermute shifts.  Loops are fully unrolled over
-    // RMAX with uniform early exits so that the register arrays keep static indices.
-    float Gr[RMAX], Sr[RMAX];
-#pragma unroll
-    for (int j = 0; j < RMAX; j++) Gr[j] = (lane < R && j < R) ? T.G[lane][j] : 0.f;
-    float lam = lane < R ? T.r_lam[lane] : 0.f;
-    const float y0v = lane < R ? T.r_y0[lane] : 0.f;
-    const bool crow = lane < nrc;           // contact row (else limit row or idle lane)
-    const int sub = crow ? lane % 3 : 0;    // position inside the contact's 3-row block
-    auto gdot = [&](float vreg) {           // (G v)[lane], v given as one value per lane
-      float acc = 0.f;
-#pragma unroll
-      for (int j = 0; j < RMAX; j++) acc += Gr[j] * rl_f(vreg, j);  // Gr[j] = 0 beyond the R live rows
-      return acc;
-    };
-    float fv = 0.f, yv = 0.f;
-    float L0 = 0.f, L1 = 0.f, L2 = 0.f;  // this row of the block-lower Cholesky factor of W: L[row][first .. first+2]
-    auto eval = [&](float y, bool want_L) {
-      // a contact's three rows are evaluated on all three lanes (the residuals come by shifts inside the block)
-      const float ya = __shfl(y, lane - sub), yb = __shfl(y, lane - sub + 1), yc = __shfl(y, lane - sub + 2);
-      float f = 0.f;
-      if (want_L) L0 = L1 = L2 = 0.f;
-      if (crow) {
-        const int k = lane / 3;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, Hc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], ya, yb, yc, f0, f1, f2, want_L ? Hc : nullptr);
-        f = sub == 0 ? f0 : (sub == 1 ? f1 : f2);
-        if (want_L) {  // Hc = L L' (positive semi-definite: a vanishing pivot zeroes its column)
-          const float l00 = Hc[0] > 1e-30f ? sqrtf(Hc[0]) : 0.f, i00 = l00 > 0.f ? 1.f / l00 : 0.f;
-          const float l10 = Hc[3] * i00, l20 = Hc[6] * i00;
-          const float d1 = Hc[4] - l10 * l10, l11 = d1 > 1e-7f * Hc[4] ? sqrtf(d1) : 0.f, i11 = l11 > 0.f ? 1.f / l11 : 0.f;
-          const float l21 = (Hc[7] - l20 * l10) * i11;
-          const float d2 = Hc[8] - l20 * l20 - l21 * l21, l22 = d2 > 1e-7f * Hc[8] ? sqrtf(d2) : 0.f;
-          if (sub == 0) { L0 = l00; } else if (sub == 1) { L0 = l10; L1 = l11; } else { L0 = l20; L1 = l21; L2 = l22; }
-        }
-      } else if (lane < R) {
-        const float D = T.r_D[lane];
-        f = y < 0.f ? -D * y : 0.f;
-        if (want_L) L0 = y < 0.f ? sqrtf(D) : 0.f;
-      }
-      return f;
-    };
-#pragma unroll 1
-    for (int it = 0; it < kMaxNewton; it++) {
-      yv = y0v + gdot(lam);
-      fv = eval(yv, true);
-      const float ev = lam - fv;
-      const float pv = gdot(ev);
-      const float gn2 = wave_sum(lane < R ? pv * ev : 0.f);
-      if ((it > 0 || c.have_ws) && gn2 <= kNewtonTol2 * scale2 + 1e-30f) break;
-      iters++;
-      // S = I + L' G L.  Column j: t_j = (G L)[lane][j] from this lane's G row and L's column j (read from the owning lanes),
-      // then S[i][j] = delta_ij + sum over the rows a >= i of i's block of L[a][i] t_j(a) (neighbour lanes, shifted in).
-      const float La1 = __shfl_down(sub == 1 ? L0 : (sub == 2 ? L1 : 0.f), 1);  // L[lane+1][lane] (the source lane picks its entry one column left of its diagonal)
-      const float La2 = __shfl_down(L0, 2);                                      // L[lane+2][lane] (only for sub == 0)
-      const float Ld = sub == 0 ? L0 : (sub == 1 ? L1 : L2);                     // L[lane][lane]
-      const bool has1 = crow && sub < 2, has2 = crow && sub == 0;
-#pragma unroll
-      for (int j = 0; j < RMAX; j++) {
-        if (j < R) {
-        float tj;
-        if (j < nrc) {
-          const int fj = j - j % 3, sj = j % 3;
-          // L[fj + b][j] for b = sj .. 2: lane fj+b holds it at position sj
-          tj = Gr[j] * rl_f(sj == 0 ? L0 : (sj == 1 ? L1 : L2), j);
-          if (sj < 2) tj += Gr[fj + sj + 1 < RMAX ? fj + sj + 1 : 0] * rl_f(sj == 0 ? L0 : L1, fj + sj + 1 < RMAX ? fj + sj + 1 : 0);
-          if (sj < 1) tj += Gr[fj + 2 < RMAX ? fj + 2 : 0] * rl_f(L0, fj + 2 < RMAX ? fj + 2 : 0);
-        } else tj = Gr[j] * rl_f(L0, j);
-        float sij = Ld * tj;
-        const float t1 = __shfl_down(tj, 1), t2 = __shfl_down(tj, 2);
-        if (has1) sij += La1 * t1;
-        if (has2) sij += La2 * t2;
-        Sr[j] = sij + (j == lane ? 1.f : 0.f);
-        } else Sr[j] = j == lane ? 1.f : 0.f;
-      }
-      // rhs = L' p
-      float w = Ld * pv;
-      {
-        const float p1 = __shfl_down(pv, 1), p2 = __shfl_down(pv, 2);
-        if (has1) w += La1 * p1;
-        if (has2) w += La2 * p2;
-      }
-      // Cholesky of S in place (row per lane; the strictly upper part is never read)
-#pragma unroll
-      for (int k = 0; k < RMAX; k++) {
-        if (k < R) {
-          const float ip = __builtin_amdgcn_rsqf(rl_f(Sr[k], k));
-          const float lik = Sr[k] * ip;
-          Sr[k] = lik;
-#pragma unroll
-          for (int j = k + 1; j < RMAX; j++) Sr[j] -= lik * rl_f(lik, j);  // rows / columns beyond R are identity: no-ops
-        }
-      }
-      const float idg = 1.f / [&]() { float dgv = 1.f;
-#pragma unroll
-        for (int j = 0; j < RMAX; j++) if (j == lane) dgv = Sr[j];
-        return dgv; }();
-      // forward substitution L_s w' = w
-#pragma unroll
-      for (int k = 0; k < RMAX; k++) {
-        if (k < R) {
-          const float wk = rl_f(w, k) * rl_f(idg, k);
-          w = lane == k ? wk : (lane > k ? w - Sr[k] * wk : w);
-        }
-      }
-      // transpose through LDS (this lane's column of L_s), then backward substitution L_s' u = w'
-      if (lane < R) {
-#pragma unroll
-        for (int j = 0; j < RMAX; j++) if (j < R) T.S[lane][j] = Sr[j];
-      }
-      DM_SYNC();
-#pragma unroll
-      for (int k = 0; k < RMAX; k++) Sr[k] = (lane < R && k < R && k >= lane) ? T.S[k][lane] : 0.f;
-      DM_SYNC();
-#pragma unroll
-      for (int k = RMAX - 1; k >= 0; k--) {
-        if (k < R) {
-          const float uk = rl_f(w, k) * rl_f(idg, k);
-          w = lane == k ? uk : (lane < k ? w - Sr[k] * uk : w);
-        }
-      }
-      // d = -e + L u, jd = G d
-      float dl = -ev + Ld * w;
-      {
-        const float u1 = __shfl_up(w, 1), u2 = __shfl_up(w, 2);
-        if (crow && sub >= 1) dl += (sub == 1 ? L0 : L1) * u1;
-        if (crow && sub == 2) dl += L0 * u2;
-      }
-      if (lane >= R) dl = 0.f;
-      const float jdv = gdot(dl);
-      const float c0s = wave_sum(lane < R ? lam * jdv : 0.f), c1s = wave_sum(lane < R ? dl * jdv : 0.f);
-      BSTAMP(9);  // newton: rows, S, Cholesky, direction
-      // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(y + alpha jd) jd
-      auto dphi = [&](float al) {
-        const float fa = eval(yv + al * jdv, false);
-        float acc = lane < R ? -fa * jdv : 0.f;
-        return c0s + al * c1s + wave_sum(acc);
-      };
-      float alpha = 0.f;
-      {
-        const float d0 = dphi(0.f);
-        if (!(d0 < 0.f)) break;  // not a descent direction any more: converged to rounding
-        float lo = 0.f, hi = 1.f, dlo = d0, dhi = dphi(1.f);
-        int guard = 0;
-        while (dhi < 0.f && fabsf(dhi) > kLsTol * fabsf(d0) && guard++ < 8) { lo = hi; dlo = dhi; hi *= 2.f; dhi = dphi(hi); }
-        if (dhi < 0.f || fabsf(dhi) <= kLsTol * fabsf(d0)) alpha = hi;  // full (or doubled) Newton step: |phi'| already small
-        else {
-#pragma unroll 1
-          for (int ls = 0; ls < kLsIter; ls++) {
-            float mid = lo - dlo * (hi - lo) / (dhi - dlo);
-            if (!(mid > lo + 0.05f * (hi - lo)) || !(mid < hi - 0.05f * (hi - lo))) mid = 0.5f * (lo + hi);
-            const float dm_ = dphi(mid);
-            if (dm_ < 0.f) { lo = mid; dlo = dm_; } else { hi = mid; dhi = dm_; }
-            if (fabsf(dm_) <= kLsTol * fabsf(d0) || hi - lo <= 1e-6f * hi) break;
-          }
-          alpha = (dhi - dlo) != 0.f ? lo - dlo * (hi - lo) / (dhi - dlo) : hi;
-          if (!(alpha >= lo) || !(alpha <= hi)) alpha = 0.5f * (lo + hi);
-        }
-      }
-      lam += alpha * dl;
-      BSTAMP(14);  // newton: line search
-    }
-    // forces at the solution
-    yv = y0v + gdot(lam);
-    fv = eval(yv, false);
-    if (lane < R) { T.r_lam[lane] = lam; T.r_y[lane] = yv; T.r_f[lane] = fv; }
-    DM_SYNC();
+    int nact_ = 0;
+    for (int k = 0; k < nc; k++) nact_ += T.c_excl[k] ? 0 : 1;
+    const int nslip = (nact_ > 0 && !(c.flags & BF_NO_NOSLIP)) ? M.noslip_iterations : 0;
+    if (R <= 16) iters = dense_newton<16>(c, R, nrc, scale2, nslip);
+    else if (R <= 24) iters = dense_newton<24>(c, R, nrc, scale2, nslip);
+    else iters = dense_newton<RMAX>(c, R, nrc, scale2, nslip);
   }
   iters_out += iters;
-  BSTAMP(15);  // newton: final forces
-  // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
-  //      unregularised A = J M^-1 J' - which is G - normal and limit forces held fixed; res = G f + (J a_s - aref)
-  int nact = 0;
-  for (int k = 0; k < nc; k++) nact += T.c_excl[k] ? 0 : 1;
-  if (nact > 0 && M.noslip_iterations > 0 && !(c.flags & BF_NO_NOSLIP)) {
-    const float scale = 1.f / (M.meaninertia * 105.f);
-    for (int iter = 0; iter < M.noslip_iterations; iter++) {
-      float improvement = 0.f;
-      for (int k = 0; k < nc; k++) {
-        if (T.c_excl[k]) continue;
-        const int r0 = 3 * k + 1, r1 = 3 * k + 2;
-        float res0 = T.r_y0[r0], res1 = T.r_y0[r1];
-        for (int q2 = 0; q2 < R; q2++) { const float fv = T.r_f[q2]; res0 += T.G[r0][q2] * fv; res1 += T.G[r1][q2] * fv; }
-        const float o0 = T.r_f[r0], o1 = T.r_f[r1];
-        const float A00 = T.G[r0][r0], A01 = T.G[r0][r1], A11 = T.G[r1][r1];
-        const float fn = T.r_f[3 * k];
-        float v0 = 0.f, v1 = 0.f;
-        if (fn >= 1e-15f) {
-          const float b0 = res0 - A00 * o0 - A01 * o1, b1 = res1 - A01 * o0 - A11 * o1, mu = T.c_mu[k];
-          const bool active = qcqp2(v0, v1, A00, A01, A11, b0, b1, mu, fn);
-          if (active) {
-            const float ssum = (v0 * v0 + v1 * v1) / (mu * mu);
-            const float sc2 = sqrtf(fn * fn / fmaxf(1e-15f, ssum));
-            v0 *= sc2; v1 *= sc2;
-          }
-        }
-        const float d0 = v0 - o0, d1 = v1 - o1;
-        // mj: costChange reverts an update whose cost change is > 1e-10 (a failed QCQP).  In float32 the two terms below cancel
-        // to ~1e-7 of their size, so the revert threshold is taken relative to them; a genuine failure is far above it.
-        const float lin_ = d0 * res0 + d1 * res1, quad_ = 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1));
-        float change = lin_ + quad_;
-        if (change > 1e-10f + 1e-4f * (fabsf(lin_) + fabsf(quad_))) { v0 = o0; v1 = o1; change = 0.f; }
-        change = fminf(change, 0.f);
-        improvement -= change;
-        DM_SYNC();
-        if (lane == 0) { T.r_f[r0] = v0; T.r_f[r1] = v1; }
-        DM_SYNC();
-      }
-      if (improvement * scale < 1e-6f) break;
-    }
-  }
   BSTAMP(16);  // noslip
   // ---- constraint forces in joint space, final acceleration a = a_s + M^-1 J' f
   if (lane < nrc) T.c_f[lane / 3][lane % 3] = constrained ? T.r_f[lane] : 0.f;
