@@ -252,13 +252,13 @@ def main():
         # FETCH_SIZE / WRITE_SIZE runs; KiB units; read side doubled per the gfx950 note in MI355X_MICROARCH.md - an
         # upper bound here, since these are 4-byte-per-lane reads, not the wide streams the x2 was calibrated on)
         traffic, traffic_src = None, None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_final_kernel.json")
-        if os.path.exists(pj) and B == ENVS_PER_GPU and not fake and not ball:
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_ball_kernel.json" if ball else "r01_pmc_final_kernel.json")
+        if os.path.exists(pj) and B == (BALL_ENVS_PER_GPU if ball else ENVS_PER_GPU) and not fake:
             with open(pj) as f:
                 pm = json.load(f)
             if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                 traffic = int((2 * pm["FETCH_SIZE"]["median"] + pm["WRITE_SIZE"]["median"]) * 1024)
-                traffic_src = "profiles/r01_pmc_final_kernel.json (2*FETCH_SIZE + WRITE_SIZE, per launch)"
+                traffic_src = "profiles/" + os.path.basename(pj) + " (2*FETCH_SIZE + WRITE_SIZE, per launch)"
         total_env_steps = world * B * args.steps
         value = total_env_steps / elapsed
         algo = BALL_ALGO_BYTES_PER_ENV_STEP if ball else ALGO_BYTES_PER_ENV_STEP

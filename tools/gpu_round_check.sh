@@ -9,3 +9,4 @@ FLYBODY_ENV_LIB=flybody_amd/csrc/variants/libflybody_env_bstamps.so timeout -k 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ball -o ball -- python3 $R/bench.py --workload walk_on_ball --no-cpu-baseline --steps 60 --warmup 10 > $R/gpurun_out/r01b_rocprof_ball.log 2>&1
 ls -R $R/gpurun_out/prof_ball | head -20
+cd $R && bash tools/pmc_ball.sh > gpurun_out/r01b_pmc_ball.log 2>&1; tail -3 gpurun_out/r01b_pmc_ball.log
