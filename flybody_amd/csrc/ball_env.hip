@@ -291,13 +291,19 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
     jpos[s] = {M.s_jpos[0][s][lane], M.s_jpos[1][s][lane], M.s_jpos[2][s][lane]};
   }
-  // joint rotations (about the link-frame axes) once, outside the level sweep
-  Q4 jq[3];
+  // Every joint of this model sits at its body's origin (checked on the host), so a link's origin does not depend on
+  // its own joint angles and everything that does not involve the parent is done once, outside the level sweep:
+  // the link's orientation relative to its parent after 0, 1, 2, 3 of its joints and the joint axes in the parent frame.
+  Q4 qrel = quat;
+  V3 axp[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
-    float sn, cs;
-    sincosf(0.5f * c.q[s], &sn, &cs);
-    jq[s] = {cs, axis[s].x * sn, axis[s].y * sn, axis[s].z * sn};
+    axp[s] = qrot(qrel, axis[s]);
+    if (s < ndof) {
+      float sn, cs;
+      sincosf(0.5f * c.q[s], &sn, &cs);
+      qrel = qmul(qrel, Q4{cs, axis[s].x * sn, axis[s].y * sn, axis[s].z * sn});
+    }
   }
   // ---- mj: mj_kinematics, one tree level per sweep
   V3 axw[3], anc[3];
@@ -307,18 +313,11 @@ __device__ __forceinline__ void stage1(Ctx &c) {
       Q4 pq = {1.f, 0.f, 0.f, 0.f};
       V3 pp = {0.f, 0.f, 0.f};
       if (parent >= 0) { const float *p = T.lk[parent]; pp = {p[0], p[1], p[2]}; pq = {p[3], p[4], p[5], p[6]}; }
-      V3 xp = pp + qrot(pq, pos);
-      Q4 xq = qmul(pq, quat);
+      const M3 Rp = q2m(pq);
+      const V3 xp = pp + mv(Rp, pos);
+      const Q4 xq = qnormalize(qmul(pq, qrel));
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
-        if (s < ndof) {
-          anc[s] = xp + qrot(xq, jpos[s]);
-          axw[s] = qrot(xq, axis[s]);
-          xq = qmul(xq, jq[s]);
-          xp = anc[s] - qrot(xq, jpos[s]);
-        }
-      }
-      xq = qnormalize(xq);
+      for (int s = 0; s < 3; s++) { axw[s] = mv(Rp, axp[s]); anc[s] = xp; }
       c.xp = xp; c.xq = xq;
       float *o = T.lk[lane];
       o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;

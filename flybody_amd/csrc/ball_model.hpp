@@ -260,7 +260,10 @@ inline BallHost build_ball_model(const Blob &b) {
     for (int s = 0; s < M.l_ndof[l]; s++) {
       int j = bjadr.i(i) + s;
       fill_slot(s, l, j);
-      for (int k = 0; k < 3; k++) { M.s_axis[k][s][l] = (float)jaxis.f(3 * j + k); M.s_jpos[k][s][l] = (float)jpos.f(3 * j + k); }
+      for (int k = 0; k < 3; k++) {
+        M.s_axis[k][s][l] = (float)jaxis.f(3 * j + k); M.s_jpos[k][s][l] = (float)jpos.f(3 * j + k);
+        if (jpos.f(3 * j + k) != 0.0) throw std::runtime_error("ball model: joints are expected at their body's origin");
+      }
     }
   }
   // ---- halteres: closed-form single hinge on the fixed thorax
