@@ -871,11 +871,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   DM_SYNC();
   BSTAMP(6);  // actuation + contact rows
-  // ---- smooth forces and accelerations (mj: mj_fwdAcceleration)
+  // ---- smooth forces (mj: mj_fwdAcceleration); the smooth acceleration a_s = M^-1 qfrc_smooth rides as column 0 of the
+  //      first block solve of the G build below
   float qs[3], am[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
-    qs[s] = 0.f;
+    qs[s] = 0.f; am[s] = 0.f;
     if (slot_on(c, s)) {
       float f = c.fnb[s];
       const int a0 = M.s_act[0][s][lane], a1 = M.s_act[1][s][lane];
@@ -883,20 +884,15 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       if (a1 >= 0) f += M.s_actcoef[1][s][lane] * T.frc[a1];
       if (nc) f += contact_gather(c, opq(c.sbl[s]), T.c_w);
       qs[s] = f;
-      T.X4[opq(c.sdof[s])] = make_float4(f, 0.f, 0.f, 0.f);
     }
   }
   V3 qsb = c.btau;
   for (int k = 0; k < nc; k++) {
     qsb.x += T.c_Jb[k][0][0] * T.c_w[k][0]; qsb.y += T.c_Jb[k][0][1] * T.c_w[k][0]; qsb.z += T.c_Jb[k][0][2] * T.c_w[k][0];
   }
-  DM_SYNC();
-  solve4(c, T.Lm, T.dinv_m);
-#pragma unroll
-  for (int s = 0; s < 3; s++) am[s] = slot_on(c, s) ? T.X4[opq(c.sdof[s])].x : 0.f;
   const float Ib = M.b_I;
   const V3 amb = (1.f / Ib) * qsb;
-  BSTAMP(7);  // smooth solve
+  BSTAMP(7);  // smooth forces
   // ---- joint-limit rows (mj: mj_instantiateLimit, margin 0): sign, D, aref per slot
   float lsgn[3], lD[3], laref[3];
 #pragma unroll
@@ -925,7 +921,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   int lrow[3] = {-1, -1, -1};
   const int nrc = 3 * nc;
   int R = nrc;
-  {  // limit rows: one per instantiated limit, in (slot, lane) order
+  {  // limit rows: one per instantiated limit, in (slot, lane) order; y0 starts as -aref, J a_s is added by the first solve
 #pragma unroll
     for (int s = 0; s < 3; s++) {
       const bool on = lsgn[s] != 0.f;
@@ -934,7 +930,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       if (on && idx < RMAX) {
         lrow[s] = idx;
         T.r_sgn[idx] = lsgn[s]; T.r_D[idx] = lD[s]; T.r_dof[idx] = (unsigned char)opq(c.sdof[s]); T.r_blk[idx] = (unsigned char)(opq(c.sbl[s]) & 0xffu);
-        T.r_y0[idx] = lsgn[s] * am[s] - laref[s];
+        T.r_y0[idx] = -laref[s];
         T.r_lam[idx] = c.have_ws ? c.wsl[s] : 0.f;
       }
       R += __popcll(bal);
@@ -943,26 +939,16 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   const bool constrained = R > 0;
   int iters = 0;
-  if (lane < nrc) { T.r_blk[lane] = (unsigned char)T.c_blk[lane / 3]; }
+  if (lane < nrc) {  // contact rows: the ball's share of J a_s minus aref; the fly's share comes with the first solve
+    const int k = lane / 3, r = lane - 3 * k;
+    T.r_blk[lane] = (unsigned char)T.c_blk[k];
+    T.r_y0[lane] = T.c_Jb[k][r][0] * amb.x + T.c_Jb[k][r][1] * amb.y + T.c_Jb[k][r][2] * amb.z - T.c_aref[k][r];
+  }
   for (int k = lane; k < 16 * 12; k += 64) (&T.rowof[0][0])[k] = 255;
-  DM_SYNC();
-  // contact rows: y0 = J a_s - aref (row-parallel), warm start from the force this link's contact carried last substep
-#pragma unroll
-  for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = am[s];
+  // warm start from the force this link's contact carried last substep
   if (c.have_ws) { for (int k = 0; k < nc; k++) if (T.c_link[k] == lane) { T.r_lam[3 * k] = c.wsc[0]; T.r_lam[3 * k + 1] = c.wsc[1]; T.r_lam[3 * k + 2] = c.wsc[2]; } }
   else if (lane < nrc) T.r_lam[lane] = 0.f;
   DM_SYNC();
-  for (int base = 0; base < nc; base += 4) {
-    const int k = base + (lane >> 4), p = lane & 15;
-    const bool on = k < nc;
-    const bool pv = on && p < T.c_nch[k];
-    const float av = pv ? T.X4[T.c_chain[k][p]].x : 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      float y = row_sum(pv ? T.c_J[k][r][p] * av : 0.f);
-      if (on && p == 0) T.r_y0[3 * k + r] = y + T.c_Jb[k][r][0] * amb.x + T.c_Jb[k][r][1] * amb.y + T.c_Jb[k][r][2] * amb.z - T.c_aref[k][r];
-    }
-  }
   // columns: a row's column is its rank among the rows of its block
   int ncol;
   {
@@ -990,20 +976,29 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       T.G[lane][r2] = gv;
     }
   }
+  // solve columns: 0 = qfrc_smooth, 1 + c = the rows whose block-local column is c
 #pragma unroll 1
-  for (int cb = 0; cb < ncol; cb += 4) {
+  for (int cb = 0; cb < ncol + 1; cb += 4) {
     for (int f = lane; f < ND; f += 64) T.X4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
     DM_SYNC();
+    if (cb == 0) {
+#pragma unroll
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])].x = qs[s];
+    }
     for (int item = lane; item < nrc * NCH; item += 64) {  // contact rows: J' over the chain
-      const int r = item / NCH, p = item - r * NCH, k = r / 3, col = (int)T.r_col[r] - cb;
+      const int r = item / NCH, p = item - r * NCH, k = r / 3, col = (int)T.r_col[r] + 1 - cb;
       if (col >= 0 && col < 4 && p < T.c_nch[k]) (&T.X4[T.c_chain[k][p]].x)[col] = T.c_J[k][r - 3 * k][p];
     }
     if (lane >= nrc && lane < R) {
-      const int col = (int)T.r_col[lane] - cb;
+      const int col = (int)T.r_col[lane] + 1 - cb;
       if (col >= 0 && col < 4) (&T.X4[T.r_dof[lane]].x)[col] = T.r_sgn[lane];
     }
     DM_SYNC();
     solve4(c, T.Lm, T.dinv_m);
+    if (cb == 0) {
+#pragma unroll
+      for (int s = 0; s < 3; s++) if (slot_on(c, s)) am[s] = T.X4[opq(c.sdof[s])].x;
+    }
     if (lane < R) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (lane < nrc) {
@@ -1021,10 +1016,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       const int b = T.r_blk[lane];
 #pragma unroll
       for (int q2 = 0; q2 < 4; q2++) {
-        const int cc = cb + q2;
-        if (cc < 12) {
-          const int r2 = T.rowof[b][cc];
-          if (r2 != 255) T.G[lane][r2] += (q2 == 0 ? acc.x : (q2 == 1 ? acc.y : (q2 == 2 ? acc.z : acc.w)));
+        const int gc = cb + q2;
+        const float av = q2 == 0 ? acc.x : (q2 == 1 ? acc.y : (q2 == 2 ? acc.z : acc.w));
+        if (gc == 0) T.r_y0[lane] += av;  // J a_s
+        else if (gc - 1 < 12) {
+          const int r2 = T.rowof[b][gc - 1];
+          if (r2 != 255) T.G[lane][r2] += av;
         }
       }
     }
