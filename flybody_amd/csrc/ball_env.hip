@@ -62,14 +62,14 @@ struct alignas(16) BTile {
     struct {
       union {
         struct { float Q[NDP], V[NDP]; };  // joint state staged for the actuators / contact rows (start of stage 2) and the observation
-        float4 X4[NDP];                     // right-hand sides / solutions of the block solves (from the smooth solve on)
+        float4 X4[NDP];                     // right-hand sides / solutions of the block solves
       };
-      float Lh[NMMAX], dinv_h[NDP];         // factor of M + h B (Euler)
+      float Mq[NMMAX], dadd[NDP];           // joint-space inertia and h * damping: only read by the stage-1 factorisation
     };
     float S[RMAX][RMAX + 1];                // Newton: I + L' G L and its Cholesky factor (no block solve is in flight then)
   };
-  float Mq[NMMAX], Lm[NMMAX];
-  float dinv_m[NDP], dadd[NDP];
+  float Lm[NMMAX], Lh[NMMAX];               // factors of M and of M + h B (Euler), made together in stage 1
+  float dinv_m[NDP], dinv_h[NDP];
   float C[NDP][6];
   union {
     float F[NDP][6];           // crb * cdof during the inertia assembly
@@ -136,7 +136,9 @@ __device__ __forceinline__ const BallModel FFE_GLOBAL &model(const Ctx &c) {
 //   L[e] -= L[ki] * L[kj] / L[kk]        (e = (i, j), i a proper ancestor of the pivot k; values stay unscaled until the end)
 // out in step order as `nfs` slots of 64 independent updates (ball_model.hpp), read coalesced and one slot ahead.
 // LDS operations of a wave complete in issue order, which is all the ordering the steps need.
-__device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, float *dst, float *dinv) {
+__device__ __forceinline__ void factor2(Ctx &c) {
+  // factorises M into T.Lm and M + diag(T.dadd) into T.Lh in one pass over the schedule (same elimination order, so the
+  // schedule words, address arithmetic and control flow are shared)
   BTile &T = *c.T;
   const BallModel FFE_GLOBAL &M = model(c);
   const int lane = c.lane;
@@ -145,14 +147,13 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
     const unsigned ea = M.ent_a[t][lane];
     if (ea >> 31) {
       const unsigned i = ea & 0xffu, j = (ea >> 8) & 0xffu, adr = (ea >> 16) & 0x3ffu;
-      float vv = src[adr];
-      if (use_add && i == j) vv += T.dadd[i];
-      dst[adr] = vv;
+      const float vv = T.Mq[adr];
+      T.Lm[adr] = vv;
+      T.Lh[adr] = i == j ? vv + T.dadd[i] : vv;
     }
   }
   DM_SYNC();
   // Schedule words are fetched one group of four slots ahead (tables are zero padded past nfs).  No fence inside the loop:
-  // a wavefront-scope release fence waits for ALL outstanding memory operations, i.e. it would stall on the prefetch;
   // the LDS accesses of consecutive slots may alias, so the compiler keeps their order, and the hardware executes a
   // wave's LDS operations in issue order.
   const int nfs = M.nfs;
@@ -170,8 +171,10 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
     for (int q = 0; q < 4; q++) {
       const unsigned a = ca[q], b = cb[q];
       if (a >> 31) {
-        const float lkk = dst[(a >> 10) & 0x3ffu], lki = dst[(a >> 20) & 0x3ffu], lkj = dst[b & 0x3ffu];
-        dst[a & 0x3ffu] -= lki * lkj * frcp(lkk);
+        const unsigned akk = (a >> 10) & 0x3ffu, aki = (a >> 20) & 0x3ffu, akj = b & 0x3ffu, ae = a & 0x3ffu;
+        const float mkk = T.Lm[akk], mki = T.Lm[aki], mkj = T.Lm[akj], hkk = T.Lh[akk], hki = T.Lh[aki], hkj = T.Lh[akj];
+        T.Lm[ae] -= mki * mkj * frcp(mkk);
+        T.Lh[ae] -= hki * hkj * frcp(hkk);
       }
     }
   }
@@ -179,13 +182,19 @@ __device__ __forceinline__ void factor(Ctx &c, const float *src, bool use_add, f
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
-    if ((ea >> 31) && (ea & 0xffu) == ((ea >> 8) & 0xffu)) dinv[ea & 0xffu] = frcp(dst[(ea >> 16) & 0x3ffu]);
+    if ((ea >> 31) && (ea & 0xffu) == ((ea >> 8) & 0xffu)) {
+      T.dinv_m[ea & 0xffu] = frcp(T.Lm[(ea >> 16) & 0x3ffu]);
+      T.dinv_h[ea & 0xffu] = frcp(T.Lh[(ea >> 16) & 0x3ffu]);
+    }
   }
   DM_SYNC();
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
     const unsigned ea = M.ent_a[t][lane];
-    if ((ea >> 31) && (ea & 0xffu) != ((ea >> 8) & 0xffu)) dst[(ea >> 16) & 0x3ffu] *= dinv[ea & 0xffu];
+    if ((ea >> 31) && (ea & 0xffu) != ((ea >> 8) & 0xffu)) {
+      T.Lm[(ea >> 16) & 0x3ffu] *= T.dinv_m[ea & 0xffu];
+      T.Lh[(ea >> 16) & 0x3ffu] *= T.dinv_h[ea & 0xffu];
+    }
   }
   DM_SYNC();
 }
@@ -251,6 +260,74 @@ __device__ __forceinline__ void solve4(Ctx &c, const float *L, const float *dinv
           const float4 xj = T.X4[j];
           float4 xi = T.X4[i];
           xi.x -= l * xj.x; xi.y -= l * xj.y; xi.z -= l * xj.z; xi.w -= l * xj.w;
+          T.X4[i] = xi;
+        }
+      }
+    }
+    DM_SYNC();
+  }
+}
+
+// Two single-right-hand-side solves with two factors of the same structure in one pass over the schedules:
+// T.X4[.].x <- (L_A D_A L_A')^-1 x, T.X4[.].y <- (L_B D_B L_B')^-1 y   (final acceleration with M, Euler with M + h B)
+__device__ __forceinline__ void solve_dual(Ctx &c, const float *LA, const float *dinvA, const float *LB, const float *dinvB) {
+  BTile &T = *c.T;
+  const BallModel FFE_GLOBAL &M = model(c);
+  const int lane = c.lane;
+  {
+    const int n = M.np1;
+    unsigned wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wq[q] = M.p1[q][lane];
+#pragma unroll 1
+    for (int base = 0; base < n; base += 4) {
+      unsigned cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) cw[q] = wq[q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) wq[q] = M.p1[base + 4 + q][lane];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const unsigned w = cw[q];
+        if (w >> 31) {
+          const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
+          const float la = LA[w & 0x3ffu], lb = LB[w & 0x3ffu];
+          const float4 xi = T.X4[i];
+          float4 xj = T.X4[j];
+          xj.x -= la * xi.x; xj.y -= lb * xi.y;
+          T.X4[j] = xj;
+        }
+      }
+    }
+    DM_SYNC();
+  }
+  for (int f = lane; f < ND; f += 64) {
+    float4 x = T.X4[f];
+    x.x *= dinvA[f]; x.y *= dinvB[f];
+    T.X4[f] = x;
+  }
+  DM_SYNC();
+  {
+    const int n = M.np2;
+    unsigned wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wq[q] = M.p2[q][lane];
+#pragma unroll 1
+    for (int base = 0; base < n; base += 4) {
+      unsigned cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) cw[q] = wq[q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) wq[q] = M.p2[base + 4 + q][lane];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const unsigned w = cw[q];
+        if (w >> 31) {
+          const unsigned i = (w >> 10) & 0x7fu, j = (w >> 17) & 0x7fu;
+          const float la = LA[w & 0x3ffu], lb = LB[w & 0x3ffu];
+          const float4 xj = T.X4[j];
+          float4 xi = T.X4[i];
+          xi.x -= la * xj.x; xi.y -= lb * xj.y;
           T.X4[i] = xi;
         }
       }
@@ -432,6 +509,8 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     if (s < ndof) { st6(T.F[opq(c.sdof[s])], mul_inert(crb, cdof[s])); st6(T.C[opq(c.sdof[s])], cdof[s]); }
   }
   if (c.xh) { st6(T.F[c.sdof[2]], S6{M.x_M[lane], 0.f, 0.f, 0.f, 0.f, 0.f}); st6(T.C[c.sdof[2]], S6{1.f, 0.f, 0.f, 0.f, 0.f, 0.f}); }
+#pragma unroll
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.dadd[opq(c.sdof[s])] = (c.flags & BF_NO_DAMPER) ? 0.f : M.h * M.s_damp[s][lane];
   DM_SYNC();
 #pragma unroll
   for (int t = 0; t < ECAP; t++) {
@@ -445,8 +524,8 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   }
   DM_SYNC();
   BSTAMP(3);  // joint forces + inertia assembly
-  factor(c, T.Mq, false, T.Lm, T.dinv_m);
-  BSTAMP(4);  // factor M
+  factor2(c);
+  BSTAMP(4);  // factor M and M + h B
   // ---- mj: mj_collision, ball (geom1, sphere) against this link's capsule: mjc_SphereCapsule
   bool hit = false;
   float dist = 0.f, margin = 0.f, gap = 0.f;
@@ -1063,20 +1142,20 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     qcb.y += T.c_Jb[k][0][1] * f0 + T.c_Jb[k][1][1] * f1 + T.c_Jb[k][2][1] * f2;
     qcb.z += T.c_Jb[k][0][2] * f0 + T.c_Jb[k][1][2] * f1 + T.c_Jb[k][2][2] * f2;
   }
-  V3 ab = amb;
-  if (constrained) {
+  // final acceleration a = a_s + M^-1 J' f and the Euler acceleration (M + h B)^-1 (qfrc_smooth + J' f) (mj: mj_Euler, implicit in
+  // the joint damping) in one pass: component x through M's factor, component y through the factor of M + h B
+  V3 ab = amb + (1.f / Ib) * qcb;
+  float qe[3];
 #pragma unroll
-    for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(qc[s], 0.f, 0.f, 0.f);
-    DM_SYNC();
-    solve4(c, T.Lm, T.dinv_m);
+  for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(qc[s], qs[s] + qc[s], 0.f, 0.f);
+  DM_SYNC();
+  solve_dual(c, T.Lm, T.dinv_m, T.Lh, T.dinv_h);
 #pragma unroll
-    for (int s = 0; s < 3; s++) a[s] = slot_on(c, s) ? am[s] + T.X4[opq(c.sdof[s])].x : 0.f;
-    ab = amb + (1.f / Ib) * qcb;
-    DM_SYNC();
-  } else {
-#pragma unroll
-    for (int s = 0; s < 3; s++) a[s] = am[s];
+  for (int s = 0; s < 3; s++) {
+    const float4 x = slot_on(c, s) ? T.X4[opq(c.sdof[s])] : make_float4(0.f, 0.f, 0.f, 0.f);
+    a[s] = am[s] + x.x; qe[s] = x.y;
   }
+  DM_SYNC();
   {
     float n2 = 0.f;
 #pragma unroll
@@ -1140,30 +1219,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   BSTAMP(18);  // sensors
   if (!integrate) return;  // mj_forward: state untouched
-  // ---- Euler with implicit joint damping (mj: mj_Euler): (M + h B) qacc_e = qfrc_smooth + qfrc_constraint
-  float damp[3];
-  bool any_damp = false;
-#pragma unroll
-  for (int s = 0; s < 3; s++) {
-    damp[s] = (slot_on(c, s) && !(c.flags & BF_NO_DAMPER)) ? M.s_damp[s][lane] : 0.f;
-    any_damp |= damp[s] > 0.f;
-  }
-  float qe[3];
-  if (__any(any_damp)) {
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-      if (slot_on(c, s)) { T.dadd[opq(c.sdof[s])] = h * damp[s]; T.X4[opq(c.sdof[s])] = make_float4(qs[s] + qc[s], 0.f, 0.f, 0.f); }
-    }
-    DM_SYNC();
-    factor(c, T.Mq, true, T.Lh, T.dinv_h);
-    solve4(c, T.Lh, T.dinv_h);
-#pragma unroll
-    for (int s = 0; s < 3; s++) qe[s] = slot_on(c, s) ? T.X4[opq(c.sdof[s])].x : 0.f;
-  } else {
-#pragma unroll
-    for (int s = 0; s < 3; s++) qe[s] = a[s];
-  }
-  DM_SYNC();
+  // ---- integrate with the Euler acceleration computed above
 #pragma unroll
   for (int s = 0; s < 3; s++) {
     if (slot_on(c, s)) { c.v[s] += h * qe[s]; c.q[s] += h * c.v[s]; }
