@@ -648,10 +648,12 @@ __device__ __forceinline__ bool qcqp2(float &x0, float &x1, float A00, float A01
 // Dense Newton of the constraint solve on R <= RB rows (RB = 16 / 24 / 32 picked per substep): lane = row, everything in
 // registers - the lane's row of G and of S = I + L' G L, other lanes' scalars by v_readlane (uniform index), neighbours'
 // by bpermute shifts.  Loops are fully unrolled over RB so that the register arrays keep static indices.
+// A real call (not inlined): the iteration loop then has the whole register file to itself - inlined, the allocator
+// kept the caller's ~90 live values resident and spilled 120-200 of the loop's own values per iteration instead.
 template <int RB>
-__device__ __forceinline__ int dense_newton(Ctx &c, const int R, const int nrc, const float scale2, const int nslip) {
-  BTile &T = *c.T;
-  const int lane = c.lane;
+__device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane, const int R, const int nrc, const float scale2, const int nslip,
+                                         const int have_ws) {
+  BTile &T = *Tp;
   int iters = 0;
     float Gr[RB], Sr[RB];
 #pragma unroll
@@ -700,7 +702,7 @@ __device__ __forceinline__ int dense_newton(Ctx &c, const int R, const int nrc, 
       const float ev = lam - fv;
       const float pv = gdot(ev);
       const float gn2 = wave_sum(lane < R ? pv * ev : 0.f);
-      if ((it > 0 || c.have_ws) && gn2 <= kNewtonTol2 * scale2 + 1e-30f) break;
+      if ((it > 0 || have_ws) && gn2 <= kNewtonTol2 * scale2 + 1e-30f) break;
       iters++;
       // S = I + L' G L.  Column j: t_j = (G L)[lane][j] from this lane's G row and L's column j (read from the owning lanes),
       // then S[i][j] = delta_ij + sum over the rows a >= i of i's block of L[a][i] t_j(a) (neighbour lanes, shifted in).
@@ -782,7 +784,6 @@ __device__ __forceinline__ int dense_newton(Ctx &c, const int R, const int nrc, 
       if (lane >= R) dl = 0.f;
       const float jdv = gdot(dl);
       const float c0s = wave_sum(lane < R ? lam * jdv : 0.f), c1s = wave_sum(lane < R ? dl * jdv : 0.f);
-      BSTAMP(9);  // newton: rows, S, Cholesky, direction
       // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(y + alpha jd) jd
       auto dphi = [&](float al) {
         const float fa = eval(yv + al * jdv, false);
@@ -811,17 +812,15 @@ __device__ __forceinline__ int dense_newton(Ctx &c, const int R, const int nrc, 
         }
       }
       lam += alpha * dl;
-      BSTAMP(14);  // newton: line search
     }
     // forces at the solution
     yv = y0v + gdot(lam);
     fv = eval(yv, false);
-    BSTAMP(15);  // newton: final forces
     // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
     //      unregularised A = J M^-1 J' - which is G - normal and limit forces held fixed; res = G f + (J a_s - aref).
     //      G is symmetric, so row r of G against f is a wave sum over the lanes' column-r entries.
     if (nslip > 0) {
-      const BallModel FFE_GLOBAL &M = model(c);
+      const BallModel FFE_GLOBAL &M = *Mp;
       const float scale = 1.f / (M.meaninertia * 105.f);
       const int nc = nrc / 3;
       for (int iter = 0; iter < nslip; iter++) {
@@ -1115,9 +1114,11 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     int nact_ = 0;
     for (int k = 0; k < nc; k++) nact_ += T.c_excl[k] ? 0 : 1;
     const int nslip = (nact_ > 0 && !(c.flags & BF_NO_NOSLIP)) ? M.noslip_iterations : 0;
-    if (R <= 16) iters = dense_newton<16>(c, R, nrc, scale2, nslip);
-    else if (R <= 24) iters = dense_newton<24>(c, R, nrc, scale2, nslip);
-    else iters = dense_newton<RMAX>(c, R, nrc, scale2, nslip);
+    ModelPtr mp_ = (ModelPtr)c.M;
+    if (R <= 16) iters = dense_newton<16>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    else if (R <= 24) iters = dense_newton<24>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    else iters = dense_newton<RMAX>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    BSTAMP(9);  // newton + noslip (dense, in registers)
   }
   iters_out += iters;
   BSTAMP(16);  // noslip
