@@ -608,15 +608,15 @@ __device__ __forceinline__ void cone_force(float D, float mu, float j0, float j1
     if (Hc) { Hc[0] = D; Hc[4] = D; Hc[8] = D; }
     return;
   }
-  const float Dm = D / fmaxf(1e-15f, mu * mu * (1.f + mu * mu)), NT = N - mu * Tn;
+  const float Dm = D * frcp(fmaxf(1e-15f, mu * mu * (1.f + mu * mu))), NT = N - mu * Tn, iT = frcp(Tn);
   f0 = -Dm * NT * mu;
-  f1 = -f0 / Tn * U1 * mu;
-  f2 = -f0 / Tn * U2 * mu;
+  f1 = -f0 * iT * U1 * mu;
+  f2 = -f0 * iT * U2 * mu;
   if (Hc) {
-    const float a = mu * N / (Tn * Tn * Tn), bd = mu * mu - mu * N / Tn, s2 = Dm * mu * mu;
+    const float a = mu * N * iT * iT * iT, bd = mu * mu - mu * N * iT, s2 = Dm * mu * mu;
     Hc[0] = s2;
-    Hc[1] = Hc[3] = s2 * (-mu * U1 / Tn);
-    Hc[2] = Hc[6] = s2 * (-mu * U2 / Tn);
+    Hc[1] = Hc[3] = s2 * (-mu * U1 * iT);
+    Hc[2] = Hc[6] = s2 * (-mu * U2 * iT);
     Hc[4] = s2 * (a * U1 * U1 + bd);
     Hc[8] = s2 * (a * U2 * U2 + bd);
     Hc[5] = Hc[7] = s2 * (a * U1 * U2);
@@ -631,12 +631,12 @@ __device__ __forceinline__ bool qcqp2(float &x0, float &x1, float A00, float A01
   for (int it = 0; it < 20; it++) {
     const float det = (P00 + la) * (P11 + la) - P01 * P01;
     if (det < 1e-10f) { x0 = x1 = 0.f; return false; }
-    const float i00 = (P11 + la) / det, i11 = (P00 + la) / det, i01 = -P01 / det;
+    const float idet = frcp(det), i00 = (P11 + la) * idet, i11 = (P00 + la) * idet, i01 = -P01 * idet;
     v0 = -i00 * B0 - i01 * B1; v1 = -i01 * B0 - i11 * B1;
     const float val = v0 * v0 + v1 * v1 - r2;
     if (val < 1e-10f) break;
     const float deriv = -2.f * (i00 * v0 * v0 + i11 * v1 * v1 + 2.f * i01 * v0 * v1);
-    const float delta = -val / deriv;
+    const float delta = -val * frcp(deriv);
     if (delta < 1e-10f) break;
     la += delta;
     active = true;
@@ -681,9 +681,9 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
         if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], ya, yb, yc, f0, f1, f2, want_L ? Hc : nullptr);
         f = sub == 0 ? f0 : (sub == 1 ? f1 : f2);
         if (want_L) {  // Hc = L L' (positive semi-definite: a vanishing pivot zeroes its column)
-          const float l00 = Hc[0] > 1e-30f ? sqrtf(Hc[0]) : 0.f, i00 = l00 > 0.f ? 1.f / l00 : 0.f;
+          const float l00 = Hc[0] > 1e-30f ? sqrtf(Hc[0]) : 0.f, i00 = l00 > 0.f ? frcp(l00) : 0.f;
           const float l10 = Hc[3] * i00, l20 = Hc[6] * i00;
-          const float d1 = Hc[4] - l10 * l10, l11 = d1 > 1e-7f * Hc[4] ? sqrtf(d1) : 0.f, i11 = l11 > 0.f ? 1.f / l11 : 0.f;
+          const float d1 = Hc[4] - l10 * l10, l11 = d1 > 1e-7f * Hc[4] ? sqrtf(d1) : 0.f, i11 = l11 > 0.f ? frcp(l11) : 0.f;
           const float l21 = (Hc[7] - l20 * l10) * i11;
           const float d2 = Hc[8] - l20 * l20 - l21 * l21, l22 = d2 > 1e-7f * Hc[8] ? sqrtf(d2) : 0.f;
           if (sub == 0) { L0 = l00; } else if (sub == 1) { L0 = l10; L1 = l11; } else { L0 = l20; L1 = l21; L2 = l22; }
