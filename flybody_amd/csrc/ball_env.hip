@@ -600,7 +600,7 @@ __device__ __forceinline__ float contact_gather(const Ctx &c, unsigned sbl, cons
 // zero force in the top zone N >= mu T, fully quadratic in the bottom zone mu N + T <= 0, and the cone-surface cost
 // Dm/2 (N - mu T)^2, Dm = D / (mu^2 (1 + mu^2)), in between.  Hc (optional) is the 3x3 Hessian of that cost in jar.
 __device__ __forceinline__ void cone_force(float D, float mu, float j0, float j1, float j2, float &f0, float &f1, float &f2, float *Hc) {
-  const float N = j0 * mu, U1 = j1 * mu, U2 = j2 * mu, Tn = sqrtf(U1 * U1 + U2 * U2);
+  const float N = j0 * mu, U1 = j1 * mu, U2 = j2 * mu, Tn = fsqrt(U1 * U1 + U2 * U2);
   if (Hc) for (int k = 0; k < 9; k++) Hc[k] = 0.f;
   if (N >= mu * Tn || (Tn <= 0.f && N >= 0.f)) { f0 = f1 = f2 = 0.f; return; }
   if (mu * N + Tn <= 0.f || (Tn <= 0.f && N < 0.f)) {
@@ -681,17 +681,17 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
         if (!T.c_excl[k]) cone_force(T.c_D[k], T.c_mu[k], ya, yb, yc, f0, f1, f2, want_L ? Hc : nullptr);
         f = sub == 0 ? f0 : (sub == 1 ? f1 : f2);
         if (want_L) {  // Hc = L L' (positive semi-definite: a vanishing pivot zeroes its column)
-          const float l00 = Hc[0] > 1e-30f ? sqrtf(Hc[0]) : 0.f, i00 = l00 > 0.f ? frcp(l00) : 0.f;
+          const float l00 = Hc[0] > 1e-30f ? fsqrt(Hc[0]) : 0.f, i00 = l00 > 0.f ? frcp(l00) : 0.f;
           const float l10 = Hc[3] * i00, l20 = Hc[6] * i00;
-          const float d1 = Hc[4] - l10 * l10, l11 = d1 > 1e-7f * Hc[4] ? sqrtf(d1) : 0.f, i11 = l11 > 0.f ? frcp(l11) : 0.f;
+          const float d1 = Hc[4] - l10 * l10, l11 = d1 > 1e-7f * Hc[4] ? fsqrt(d1) : 0.f, i11 = l11 > 0.f ? frcp(l11) : 0.f;
           const float l21 = (Hc[7] - l20 * l10) * i11;
-          const float d2 = Hc[8] - l20 * l20 - l21 * l21, l22 = d2 > 1e-7f * Hc[8] ? sqrtf(d2) : 0.f;
+          const float d2 = Hc[8] - l20 * l20 - l21 * l21, l22 = d2 > 1e-7f * Hc[8] ? fsqrt(d2) : 0.f;
           if (sub == 0) { L0 = l00; } else if (sub == 1) { L0 = l10; L1 = l11; } else { L0 = l20; L1 = l21; L2 = l22; }
         }
       } else if (lane < R) {
         const float D = T.r_D[lane];
         f = y < 0.f ? -D * y : 0.f;
-        if (want_L) L0 = y < 0.f ? sqrtf(D) : 0.f;
+        if (want_L) L0 = y < 0.f ? fsqrt(D) : 0.f;
       }
       return f;
     };
@@ -746,10 +746,10 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
           for (int j = k + 1; j < RB; j++) Sr[j] -= lik * rl_f(lik, j);  // rows / columns beyond R are identity: no-ops
         }
       }
-      const float idg = 1.f / [&]() { float dgv = 1.f;
+      const float idg = frcp([&]() { float dgv = 1.f;
 #pragma unroll
         for (int j = 0; j < RB; j++) if (j == lane) dgv = Sr[j];
-        return dgv; }();
+        return dgv; }());
       // forward substitution L_s w' = w
 #pragma unroll
       for (int k = 0; k < RB; k++) {
@@ -1044,12 +1044,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   DM_SYNC();
   // G: ball coupling between contact rows, then the fly part M_blk^-1 from the block solves
+  const float iIb = 1.f / Ib;
   if (lane < R) {
     for (int r2 = 0; r2 < R; r2++) {
       float gv = 0.f;
       if (lane < nrc && r2 < nrc) {
         const float *ja = T.c_Jb[lane / 3][lane % 3], *jb = T.c_Jb[r2 / 3][r2 % 3];
-        gv = (ja[0] * jb[0] + ja[1] * jb[1] + ja[2] * jb[2]) / Ib;
+        gv = (ja[0] * jb[0] + ja[1] * jb[1] + ja[2] * jb[2]) * iIb;
       }
       T.G[lane][r2] = gv;
     }

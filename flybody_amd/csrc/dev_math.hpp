@@ -103,6 +103,13 @@ __device__ __forceinline__ float frcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   return r * (2.f - x * r);
 }
+// sqrt(x) as x * rsq(x) with one Newton step on the reciprocal square root (full float32 accuracy, no IEEE fix-up code)
+__device__ __forceinline__ float fsqrt(float x) {
+  if (!(x > 0.f)) return 0.f;
+  float r = __builtin_amdgcn_rsqf(x);
+  r = r * (1.5f - 0.5f * x * r * r);
+  return x * r;
+}
 
 // One workgroup = one wavefront: LDS operations of a wave execute in issue order, so publishing a lane's LDS write to
 // the other lanes only needs the compiler not to reorder across this point.
