@@ -11,10 +11,10 @@ import torch
 
 from flybody_amd import _capi, fly_envs
 
-NAMES = ["kinematics sweep", "velocity sweep", "body forces + subtree sweep", "joint forces + M assembly", "factor M", "collision",
-         "actuation + contact rows", "smooth solve", "rows + G (block solves)", "newton: rows, S, Cholesky, direction", "-", "-",
-         "-", "-", "newton: line search", "newton: final forces", "noslip", "constraint forces + final solve", "sensors",
-         "Euler", "prologue + store"]
+NAMES = ["kinematics sweep", "velocity sweep", "body forces + subtree sweep", "joint forces + M assembly", "factor M and M + hB", "collision",
+         "actuation + contact rows", "smooth forces", "rows + G (block solves incl. a_s)", "newton + noslip (dense, registers)", "-", "-",
+         "-", "-", "-", "-", "-", "constraint forces + final/Euler solve", "sensors",
+         "integration", "prologue + store"]
 B = 4096
 env = fly_envs.walk_on_ball(batch_size=B)
 env.reset()
