@@ -74,7 +74,7 @@ struct alignas(16) BTile {
   union {
     float F[NDP][6];           // crb * cdof during the inertia assembly
     float lk[NL][12];          // link exchange of the level sweeps: pose (7) | velocity + acceleration (12) | crb (10) | force (6)
-    float G[RMAX][RMAX + 1];   // stage 2: G = J M^-1 J' over the constraint rows (until the sensor sweeps)
+    float G[RMAX * (RMAX + 1) / 2];  // stage 2: G = J M^-1 J' over the constraint rows, lower triangle packed by rows (lane r owns row r)
   };
   float frc[64];
   int c_link[NC], c_blk[NC], c_excl[NC], c_nch[NC], c_adh[NC];
@@ -85,7 +85,7 @@ struct alignas(16) BTile {
   float c_J[NC][3][NCH], c_Jb[NC][3][3];
   float c_D[NC], c_mu[NC], c_aref[NC][3], c_f[NC][3], c_w[NC][3];
   // constraint rows: 3 per contact (normal, two tangents), then the instantiated joint limits
-  float r_y0[RMAX], r_lam[RMAX], r_f[RMAX], r_y[RMAX], r_e[RMAX], r_d[RMAX], r_jd[RMAX], r_u[RMAX], r_L[RMAX][3];
+  float r_y0[RMAX], r_lam[RMAX], r_f[RMAX];
   float r_sgn[RMAX], r_D[RMAX];
   unsigned char r_blk[RMAX], r_col[RMAX], r_dof[RMAX], rowof[16][12];
   float sens[24];  // running sums of the buffered sensors: force 18, touch 6
@@ -362,12 +362,9 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
   const V3 pos = {M.l_pos[0][lane], M.l_pos[1][lane], M.l_pos[2][lane]};
   const Q4 quat = {M.l_quat[0][lane], M.l_quat[1][lane], M.l_quat[2][lane], M.l_quat[3][lane]};
-  V3 axis[3], jpos[3];
+  V3 axis[3];
 #pragma unroll
-  for (int s = 0; s < 3; s++) {
-    axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
-    jpos[s] = {M.s_jpos[0][s][lane], M.s_jpos[1][s][lane], M.s_jpos[2][s][lane]};
-  }
+  for (int s = 0; s < 3; s++) axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
   // Every joint of this model sits at its body's origin (checked on the host), so a link's origin does not depend on
   // its own joint angles and everything that does not involve the parent is done once, outside the level sweep:
   // the link's orientation relative to its parent after 0, 1, 2, 3 of its joints and the joint axes in the parent frame.
@@ -657,7 +654,7 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
   int iters = 0;
     float Gr[RB], Sr[RB];
 #pragma unroll
-    for (int j = 0; j < RB; j++) Gr[j] = (lane < R && j < R) ? T.G[lane][j] : 0.f;
+    for (int j = 0; j < RB; j++) Gr[j] = (lane < R && j < R) ? T.G[j <= lane ? lane * (lane + 1) / 2 + j : j * (j + 1) / 2 + lane] : 0.f;
     float lam = lane < R ? T.r_lam[lane] : 0.f;
     const float y0v = lane < R ? T.r_y0[lane] : 0.f;
     const bool crow = lane < nrc;           // contact row (else limit row or idle lane)
@@ -855,7 +852,7 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
         if (improvement * scale < 1e-6f) break;
       }
     }
-    if (lane < R) { T.r_lam[lane] = lam; T.r_y[lane] = yv; T.r_f[lane] = fv; }
+    if (lane < R) { T.r_lam[lane] = lam; T.r_f[lane] = fv; }
     DM_SYNC();
   return iters;
 }
@@ -1045,14 +1042,15 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   DM_SYNC();
   // G: ball coupling between contact rows, then the fly part M_blk^-1 from the block solves
   const float iIb = 1.f / Ib;
+  const int gtri = lane * (lane + 1) / 2;  // G is symmetric: row `lane` keeps its columns r2 <= lane
   if (lane < R) {
-    for (int r2 = 0; r2 < R; r2++) {
+    for (int r2 = 0; r2 <= lane; r2++) {
       float gv = 0.f;
       if (lane < nrc && r2 < nrc) {
         const float *ja = T.c_Jb[lane / 3][lane % 3], *jb = T.c_Jb[r2 / 3][r2 % 3];
         gv = (ja[0] * jb[0] + ja[1] * jb[1] + ja[2] * jb[2]) * iIb;
       }
-      T.G[lane][r2] = gv;
+      T.G[gtri + r2] = gv;
     }
   }
   // solve columns: 0 = qfrc_smooth, 1 + c = the rows whose block-local column is c
@@ -1100,7 +1098,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         if (gc == 0) T.r_y0[lane] += av;  // J a_s
         else if (gc - 1 < 12) {
           const int r2 = T.rowof[b][gc - 1];
-          if (r2 != 255) T.G[lane][r2] += av;
+          if (r2 <= lane) T.G[gtri + r2] += av;  // (255 = no such row)
         }
       }
     }
