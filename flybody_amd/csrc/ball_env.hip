@@ -692,8 +692,10 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
       }
       return f;
     };
+    bool fresh = false;  // yv, fv belong to the current lam
 #pragma unroll 1
     for (int it = 0; it < kMaxNewton; it++) {
+      fresh = true;
       yv = y0v + gdot(lam);
       fv = eval(yv, true);
       const float ev = lam - fv;
@@ -809,10 +811,13 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
         }
       }
       lam += alpha * dl;
+      fresh = false;
     }
     // forces at the solution
-    yv = y0v + gdot(lam);
-    fv = eval(yv, false);
+    if (!fresh) {
+      yv = y0v + gdot(lam);
+      fv = eval(yv, false);
+    }
     // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
     //      unregularised A = J M^-1 J' - which is G - normal and limit forces held fixed; res = G f + (J a_s - aref).
     //      G is symmetric, so row r of G against f is a wave sum over the lanes' column-r entries.
@@ -820,13 +825,14 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
       const BallModel FFE_GLOBAL &M = *Mp;
       const float scale = 1.f / (M.meaninertia * 105.f);
       const int nc = nrc / 3;
+      float res = y0v + gdot(fv);  // residual row per lane, kept current as the tangential forces move (G is symmetric)
       for (int iter = 0; iter < nslip; iter++) {
         float improvement = 0.f;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
           if (3 * k + 2 < RB && k < nc && !T.c_excl[k]) {
             const int r0 = 3 * k + 1, r1 = 3 * k + 2;
-            const float res0 = rl_f(y0v, r0) + wave_sum(Gr[r0] * fv), res1 = rl_f(y0v, r1) + wave_sum(Gr[r1] * fv);
+            const float res0 = rl_f(res, r0), res1 = rl_f(res, r1);
             const float o0 = rl_f(fv, r0), o1 = rl_f(fv, r1), fn = rl_f(fv, 3 * k);
             const float A00 = rl_f(Gr[r0], r0), A01 = rl_f(Gr[r1], r0), A11 = rl_f(Gr[r1], r1);
             float v0 = 0.f, v1 = 0.f;
@@ -834,19 +840,20 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
               const float b0 = res0 - A00 * o0 - A01 * o1, b1 = res1 - A01 * o0 - A11 * o1, mu = T.c_mu[k];
               const bool active = qcqp2(v0, v1, A00, A01, A11, b0, b1, mu, fn);
               if (active) {
-                const float ssum = (v0 * v0 + v1 * v1) / (mu * mu);
-                const float sc2 = sqrtf(fn * fn / fmaxf(1e-15f, ssum));
+                const float ssum = (v0 * v0 + v1 * v1) * frcp(mu * mu);
+                const float sc2 = fn * __builtin_amdgcn_rsqf(fmaxf(1e-15f, ssum));
                 v0 *= sc2; v1 *= sc2;
               }
             }
-            const float d0 = v0 - o0, d1 = v1 - o1;
+            float d0 = v0 - o0, d1 = v1 - o1;
             // mj: costChange reverts an update whose cost change is > 1e-10 (a failed QCQP).  In float32 the two terms below
             // cancel to ~1e-7 of their size, so the threshold is taken relative to them; a genuine failure is far above it.
             const float lin_ = d0 * res0 + d1 * res1, quad_ = 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1));
             float change = lin_ + quad_;
-            if (change > 1e-10f + 1e-4f * (fabsf(lin_) + fabsf(quad_))) { v0 = o0; v1 = o1; change = 0.f; }
+            if (change > 1e-10f + 1e-4f * (fabsf(lin_) + fabsf(quad_))) { v0 = o0; v1 = o1; d0 = d1 = 0.f; change = 0.f; }
             improvement -= fminf(change, 0.f);
             fv = lane == r0 ? v0 : (lane == r1 ? v1 : fv);
+            res += Gr[r0] * d0 + Gr[r1] * d1;
           }
         }
         if (improvement * scale < 1e-6f) break;
