@@ -705,10 +705,13 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
       iters++;
       // S = I + L' G L.  Column j: t_j = (G L)[lane][j] from this lane's G row and L's column j (read from the owning lanes),
       // then S[i][j] = delta_ij + sum over the rows a >= i of i's block of L[a][i] t_j(a) (neighbour lanes, shifted in).
-      const float La1 = __shfl_down(sub == 1 ? L0 : (sub == 2 ? L1 : 0.f), 1);  // L[lane+1][lane] (the source lane picks its entry one column left of its diagonal)
-      const float La2 = __shfl_down(L0, 2);                                      // L[lane+2][lane] (only for sub == 0)
-      const float Ld = sub == 0 ? L0 : (sub == 1 ? L1 : L2);                     // L[lane][lane]
+      // wshl1(x): lane i takes lane i + 1's x (DPP wave shift: no LDS round trip, unlike a bpermute)
       const bool has1 = crow && sub < 2, has2 = crow && sub == 0;
+      // (shifts are whole-wave operations: taken unconditionally, selected afterwards)
+      const float Ls1 = wshl1(sub == 1 ? L0 : (sub == 2 ? L1 : 0.f)), Ls2 = wshl1(wshl1(L0));
+      const float La1 = has1 ? Ls1 : 0.f;  // L[lane+1][lane] (the source lane picks its entry one column left of its diagonal)
+      const float La2 = has2 ? Ls2 : 0.f;  // L[lane+2][lane] (only for sub == 0)
+      const float Ld = sub == 0 ? L0 : (sub == 1 ? L1 : L2);                         // L[lane][lane]
 #pragma unroll
       for (int j = 0; j < RB; j++) {
         if (j < R) {
@@ -720,65 +723,56 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
           if (sj < 2) tj += Gr[fj + sj + 1 < RB ? fj + sj + 1 : 0] * rl_f(sj == 0 ? L0 : L1, fj + sj + 1 < RB ? fj + sj + 1 : 0);
           if (sj < 1) tj += Gr[fj + 2 < RB ? fj + 2 : 0] * rl_f(L0, fj + 2 < RB ? fj + 2 : 0);
         } else tj = Gr[j] * rl_f(L0, j);
-        float sij = Ld * tj;
-        const float t1 = __shfl_down(tj, 1), t2 = __shfl_down(tj, 2);
-        if (has1) sij += La1 * t1;
-        if (has2) sij += La2 * t2;
-        Sr[j] = sij + (j == lane ? 1.f : 0.f);
+        const float t1 = wshl1(tj), t2 = wshl1(t1);
+        Sr[j] = (j == lane ? 1.f : 0.f) + Ld * tj + La1 * t1 + La2 * t2;
         } else Sr[j] = j == lane ? 1.f : 0.f;
       }
       // rhs = L' p
-      float w = Ld * pv;
+      float w;
       {
-        const float p1 = __shfl_down(pv, 1), p2 = __shfl_down(pv, 2);
-        if (has1) w += La1 * p1;
-        if (has2) w += La2 * p2;
+        const float p1 = wshl1(pv), p2 = wshl1(p1);
+        w = Ld * pv + La1 * p1 + La2 * p2;
       }
-      // Cholesky of S in place (row per lane; the strictly upper part is never read)
+      // Cholesky of S (row per lane) as S = Lt D Lt', Lt unit lower triangular: Sr[k] ends as Lt[lane][k] below the diagonal and 0
+      // on and above it, so that the substitutions are one unconditional FMA per step; ipp = 1 / D[lane]
+      float ipp = 1.f;
 #pragma unroll
       for (int k = 0; k < RB; k++) {
         if (k < R) {
           const float ip = __builtin_amdgcn_rsqf(rl_f(Sr[k], k));
           const float lik = Sr[k] * ip;
-          Sr[k] = lik;
 #pragma unroll
           for (int j = k + 1; j < RB; j++) Sr[j] -= lik * rl_f(lik, j);  // rows / columns beyond R are identity: no-ops
+          Sr[k] = lane > k ? lik * ip : 0.f;
+          ipp = lane == k ? ip * ip : ipp;
         }
       }
-      const float idg = frcp([&]() { float dgv = 1.f;
+      // forward substitution Lt z = w
 #pragma unroll
-        for (int j = 0; j < RB; j++) if (j == lane) dgv = Sr[j];
-        return dgv; }());
-      // forward substitution L_s w' = w
-#pragma unroll
-      for (int k = 0; k < RB; k++) {
-        if (k < R) {
-          const float wk = rl_f(w, k) * rl_f(idg, k);
-          w = lane == k ? wk : (lane > k ? w - Sr[k] * wk : w);
-        }
-      }
-      // transpose through LDS (this lane's column of L_s), then backward substitution L_s' u = w'
+      for (int k = 0; k < RB; k++)
+        if (k < R) w -= Sr[k] * rl_f(w, k);
+      w *= ipp;
+      // transpose through LDS (this lane's column of Lt), then backward substitution Lt' u = D^-1 z
       if (lane < R) {
 #pragma unroll
         for (int j = 0; j < RB; j++) if (j < R) T.S[lane][j] = Sr[j];
       }
       DM_SYNC();
 #pragma unroll
-      for (int k = 0; k < RB; k++) Sr[k] = (lane < R && k < R && k >= lane) ? T.S[k][lane] : 0.f;
+      for (int k = 0; k < RB; k++) Sr[k] = 0.f;
+      if (lane < R) {
+#pragma unroll
+        for (int k = 0; k < RB; k++) if (k < R) Sr[k] = T.S[k][lane];
+      }
       DM_SYNC();
 #pragma unroll
-      for (int k = RB - 1; k >= 0; k--) {
-        if (k < R) {
-          const float uk = rl_f(w, k) * rl_f(idg, k);
-          w = lane == k ? uk : (lane < k ? w - Sr[k] * uk : w);
-        }
-      }
+      for (int k = RB - 1; k >= 0; k--)
+        if (k < R) w -= Sr[k] * rl_f(w, k);
       // d = -e + L u, jd = G d
-      float dl = -ev + Ld * w;
+      float dl;
       {
-        const float u1 = __shfl_up(w, 1), u2 = __shfl_up(w, 2);
-        if (crow && sub >= 1) dl += (sub == 1 ? L0 : L1) * u1;
-        if (crow && sub == 2) dl += L0 * u2;
+        const float u1 = wshr1(w), u2 = wshr1(u1);
+        dl = -ev + Ld * w + (crow && sub >= 1 ? (sub == 1 ? L0 : L1) : 0.f) * u1 + (crow && sub == 2 ? L0 : 0.f) * u2;
       }
       if (lane >= R) dl = 0.f;
       const float jdv = gdot(dl);

@@ -81,6 +81,9 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
+// whole-wave shifts by one lane (DPP wave_shl:1 / wave_shr:1): lane i takes lane i + 1's (i - 1's) value; the end lane gets 0
+__device__ __forceinline__ float wshl1(float v) { return dpp_move<0x130>(v); }
+__device__ __forceinline__ float wshr1(float v) { return dpp_move<0x138>(v); }
 // full-wave sum, result in every lane (DPP folds inside each row of 16, then four v_readlane)
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_move<0xB1>(v);
