@@ -342,12 +342,12 @@ __device__ __forceinline__ float impedance(const float *si, float x) {
   float d0 = fminf(fmaxf(si[0], 1e-4f), 0.9999f), d1 = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
   const float width = fmaxf(0.f, si[2]), mid = fminf(fmaxf(si[3], 1e-4f), 0.9999f), power = fmaxf(1.f, si[4]);
   if (d0 == d1 || width <= 1e-15f) return 0.5f * (d0 + d1);
-  x = x / width;
+  x = x * frcp(width);
   if (x >= 1.f) return d1;
   if (x <= 0.f) return d0;
   float y;
   if (power == 1.f) y = x;
-  else if (power == 2.f) y = x <= mid ? x * x / mid : 1.f - (1.f - x) * (1.f - x) / (1.f - mid);
+  else if (power == 2.f) y = x <= mid ? x * x * frcp(mid) : 1.f - (1.f - x) * (1.f - x) * frcp(1.f - mid);
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
   else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
   return d0 + y * (d1 - d0);
@@ -534,10 +534,10 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     const float half = M.g_half[lane], rad = M.g_rad[lane], x = fminf(fmaxf(dot(ax, bc - gp), -half), half);
     margin = M.g_margin[lane]; gap = M.g_gap[lane];
     const V3 dif = gp + x * ax - bc;
-    const float cd = sqrtf(dot(dif, dif));
+    const float cd = fsqrt(dot(dif, dif));
     dist = cd - M.b_radius - rad;
     hit = cd <= margin + M.b_radius + rad;
-    if (cd >= 1e-15f) nrm = (1.f / cd) * dif;
+    if (cd >= 1e-15f) nrm = frcp(cd) * dif;
     cpos = bc + (M.b_radius + 0.5f * dist) * nrm;
   }
   const unsigned long long bal = __ballot(hit);
@@ -560,7 +560,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     // mj: mju_makeFrame
     V3 t1 = (nrm.y < 0.5f && nrm.y > -0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
     t1 = t1 - dot(nrm, t1) * nrm;
-    t1 = (1.f / sqrtf(dot(t1, t1))) * t1;
+    t1 = frcp(fsqrt(dot(t1, t1))) * t1;
     const V3 t2 = cross(nrm, t1);
     float *fr = T.c_frame[idx];
     fr[0] = nrm.x; fr[1] = nrm.y; fr[2] = nrm.z; fr[3] = t1.x; fr[4] = t1.y; fr[5] = t1.z; fr[6] = t2.x; fr[7] = t2.y; fr[8] = t2.z;
@@ -877,7 +877,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     if (!(c.flags & BF_NO_ACTUATION)) {
       float ctrl = ctrl_reg;
       if (M.a_climited[lane]) ctrl = fminf(fmaxf(ctrl, M.a_clo[lane]), M.a_chi[lane]);
-      act_dot = (ctrl - act_reg) / M.a_tau[lane];
+      act_dot = (ctrl - act_reg) * frcp(M.a_tau[lane]);
       float length = 0.f, vel = 0.f;
       const int nw = M.a_nwrap[lane];
       for (int w = 0; w < nw; w++) { const int f = M.a_wdof[w][lane]; const float cf = M.a_wcoef[w][lane]; length += cf * T.Q[f]; vel += cf * T.V[f]; }
@@ -935,8 +935,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 #pragma unroll
       for (int q2 = 0; q2 < 5; q2++) si_[q2] = M.c_solimp[q2];
       const float imp = impedance(si_, fabsf(dist - incl));
-      const float R0 = fmaxf(1e-15f, (1.f - imp) * invw / imp);
-      T.c_D[k] = T.c_excl[k] ? 0.f : 1.f / R0;
+      const float R0 = fmaxf(1e-15f, (1.f - imp) * invw * frcp(imp));
+      T.c_D[k] = T.c_excl[k] ? 0.f : frcp(R0);
       T.c_mu[k] = T.c_par[k][3];
       T.c_aref[k][0] = -B * vel[0] - K * imp * (dist - incl);
       T.c_aref[k][1] = -B * vel[1];
@@ -967,7 +967,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     qsb.x += T.c_Jb[k][0][0] * T.c_w[k][0]; qsb.y += T.c_Jb[k][0][1] * T.c_w[k][0]; qsb.z += T.c_Jb[k][0][2] * T.c_w[k][0];
   }
   const float Ib = M.b_I;
-  const V3 amb = (1.f / Ib) * qsb;
+  const V3 amb = frcp(Ib) * qsb;
   BSTAMP(7);  // smooth forces
   // ---- joint-limit rows (mj: mj_instantiateLimit, margin 0): sign, D, aref per slot
   float lsgn[3], lD[3], laref[3];
@@ -984,7 +984,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 #pragma unroll
         for (int q2 = 0; q2 < 5; q2++) si_[q2] = M.j_solimp[q2];
         const float imp = impedance(si_, fabsf(dist));
-        lD[s] = 1.f / fmaxf(1e-15f, (1.f - imp) * M.s_invw[s][lane] / imp);
+        lD[s] = frcp(fmaxf(1e-15f, (1.f - imp) * M.s_invw[s][lane] * frcp(imp)));
         laref[s] = -M.s_B[s][lane] * (lsgn[s] * c.v[s]) - M.s_K[s][lane] * imp * dist;
       }
     }
@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   DM_SYNC();
   // G: ball coupling between contact rows, then the fly part M_blk^-1 from the block solves
-  const float iIb = 1.f / Ib;
+  const float iIb = frcp(Ib);
   const int gtri = lane * (lane + 1) / 2;  // G is symmetric: row `lane` keeps its columns r2 <= lane
   if (lane < R) {
     for (int r2 = 0; r2 <= lane; r2++) {
@@ -1145,7 +1145,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   }
   // final acceleration a = a_s + M^-1 J' f and the Euler acceleration (M + h B)^-1 (qfrc_smooth + J' f) (mj: mj_Euler, implicit in
   // the joint damping) in one pass: component x through M's factor, component y through the factor of M + h B
-  V3 ab = amb + (1.f / Ib) * qcb;
+  V3 ab = amb + frcp(Ib) * qcb;
   float qe[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) if (slot_on(c, s)) T.X4[opq(c.sdof[s])] = make_float4(qc[s], qs[s] + qc[s], 0.f, 0.f);
@@ -1228,9 +1228,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   // ball: no damping, so its Euler acceleration is ab = (tau_smooth + J_b' f) / I
   c.bw = c.bw + h * ab;
   {
-    const float wn = sqrtf(dot(c.bw, c.bw));
+    const float wn = fsqrt(dot(c.bw, c.bw));
     if (wn >= 1e-15f) {
-      const Q4 dq = axis_angle((1.f / wn) * c.bw, wn * h);
+      const Q4 dq = axis_angle(frcp(wn) * c.bw, wn * h);
       c.bq = qnormalize(qmul(qnormalize(c.bq), dq));
     }
   }
