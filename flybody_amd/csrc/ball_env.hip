@@ -1029,9 +1029,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   int ncol;
   {
     int mycol = 0;
+    const int myb = lane < R ? (int)T.r_blk[lane] : -1;
+    for (int b = 0; b < NBLK; b++) {  // rank among the lower rows of the same block, by ballots
+      const unsigned long long mb = __ballot(myb == b);
+      if (myb == b) mycol = __popcll(mb & ((1ull << lane) - 1ull));
+    }
     if (lane < R) {
-      const int b = T.r_blk[lane];
-      for (int r2 = 0; r2 < lane; r2++) mycol += (T.r_blk[r2] == b);
+      const int b = myb;
       T.r_col[lane] = (unsigned char)mycol;
       if (mycol < 12) T.rowof[b][mycol] = (unsigned char)lane; else c.overflow = 1;
       mycol += 1;
@@ -1044,14 +1048,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   // G: ball coupling between contact rows, then the fly part M_blk^-1 from the block solves
   const float iIb = frcp(Ib);
   const int gtri = lane * (lane + 1) / 2;  // G is symmetric: row `lane` keeps its columns r2 <= lane
-  if (lane < R) {
-    for (int r2 = 0; r2 <= lane; r2++) {
-      float gv = 0.f;
-      if (lane < nrc && r2 < nrc) {
-        const float *ja = T.c_Jb[lane / 3][lane % 3], *jb = T.c_Jb[r2 / 3][r2 % 3];
-        gv = (ja[0] * jb[0] + ja[1] * jb[1] + ja[2] * jb[2]) * iIb;
-      }
-      T.G[gtri + r2] = gv;
+  {
+    V3 ja = {0.f, 0.f, 0.f};  // this row's ball Jacobian (zero for limit rows); the other rows' come by v_readlane
+    if (lane < nrc) { const float *jp = T.c_Jb[lane / 3][lane % 3]; ja = {jp[0] * iIb, jp[1] * iIb, jp[2] * iIb}; }
+    for (int r2 = 0; r2 < R; r2++) {
+      const float gv = (ja.x * rl_f(ja.x, r2) + ja.y * rl_f(ja.y, r2) + ja.z * rl_f(ja.z, r2)) * Ib;
+      if (lane < R && r2 <= lane) T.G[gtri + r2] = gv;
     }
   }
   // solve columns: 0 = qfrc_smooth, 1 + c = the rows whose block-local column is c
