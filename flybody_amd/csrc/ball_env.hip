@@ -98,7 +98,7 @@ struct Ctx {
   const BallModel *M;
   BTile *T;
   int lane, flags;
-  unsigned lpack, lkids;  // parent + 1 | depth << 8 | ndof << 12 ;  children | nchild << 24
+  unsigned lpack;         // parent + 1 | depth << 8 | ndof << 12
   int sdof[3];
   unsigned sbl[3];        // block | local index << 8 of each slot's dof
   float q[3], v[3], fnb[3];
@@ -119,7 +119,6 @@ struct Ctx {
 
 __device__ __forceinline__ bool slot_on(const Ctx &c, int s) { return c.sdof[s] >= 0; }
 __device__ __forceinline__ int l_parent(const Ctx &c) { return (int)(c.lpack & 0xffu) - 1; }
-__device__ __forceinline__ int l_depth(const Ctx &c) { return (int)((c.lpack >> 8) & 0xfu); }
 __device__ __forceinline__ int l_ndof(const Ctx &c) { return (int)((c.lpack >> 12) & 0x3u); }
 // The tables are read through an address-space-1 pointer: a generic pointer makes every table read a FLAT load, which
 // counts against the LDS wait counter as well, so each LDS wait would also wait for the schedule prefetch.
@@ -357,8 +356,7 @@ __device__ __forceinline__ float impedance(const float *si, float x) {
 __device__ __forceinline__ void stage1(Ctx &c) {
   BTile &T = *c.T;
   const BallModel FFE_GLOBAL &M = model(c);
-  const int lane = c.lane, depth = l_depth(c), parent = l_parent(c), ndof = l_ndof(c);
-  const int nchild = (int)(c.lkids >> 24), ch0 = (int)(c.lkids & 0xffu), ch1 = (int)((c.lkids >> 8) & 0xffu), ch2 = (int)((c.lkids >> 16) & 0xffu);
+  const int lane = c.lane, parent = l_parent(c), ndof = l_ndof(c);
   const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
   const V3 pos = {M.l_pos[0][lane], M.l_pos[1][lane], M.l_pos[2][lane]};
   const Q4 quat = {M.l_quat[0][lane], M.l_quat[1][lane], M.l_quat[2][lane], M.l_quat[3][lane]};
@@ -379,23 +377,40 @@ __device__ __forceinline__ void stage1(Ctx &c) {
       qrel = qmul(qrel, Q4{cs, axis[s].x * sn, axis[s].y * sn, axis[s].z * sn});
     }
   }
-  // ---- mj: mj_kinematics, one tree level per sweep
+  // ---- mj: mj_kinematics by pointer jumping instead of one sweep per tree level: after round r the pose (xp, xq) is
+  //      relative to the frame above the link's 2^(r+1)-th ancestor; three rounds cover the deepest chain (8 links) with every
+  //      lane at work in every round (a level sweep runs its body once per level with one level's lanes active).
+  const unsigned tree = M.l_tree[lane];
+  const int sub = (int)(tree & 0xffu), anc2 = (int)((tree >> 8) & 0xffu) - 1, anc4 = (int)((tree >> 16) & 0xffu) - 1;
   V3 axw[3], anc[3];
-#pragma unroll 1
-  for (int d = 1; d <= M.maxdepth; d++) {
-    if (depth == d) {
-      Q4 pq = {1.f, 0.f, 0.f, 0.f};
-      V3 pp = {0.f, 0.f, 0.f};
-      if (parent >= 0) { const float *p = T.lk[parent]; pp = {p[0], p[1], p[2]}; pq = {p[3], p[4], p[5], p[6]}; }
-      const M3 Rp = q2m(pq);
-      const V3 xp = pp + mv(Rp, pos);
-      const Q4 xq = qnormalize(qmul(pq, qrel));
+  {
+    V3 xp = pos;
+    Q4 xq = qrel;
 #pragma unroll
-      for (int s = 0; s < 3; s++) { axw[s] = mv(Rp, axp[s]); anc[s] = xp; }
-      c.xp = xp; c.xq = xq;
+    for (int r = 0; r < 3; r++) {
+      const int a = r == 0 ? parent : (r == 1 ? anc2 : anc4);
       float *o = T.lk[lane];
       o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
+      DM_SYNC();
+      if (a >= 0) {
+        const float *p = T.lk[a];
+        const V3 pp = {p[0], p[1], p[2]};
+        const Q4 pq = {p[3], p[4], p[5], p[6]};
+        xp = pp + mv(q2m(pq), xp);
+        xq = qmul(pq, xq);
+      }
+      DM_SYNC();
     }
+    xq = qnormalize(xq);
+    c.xp = xp; c.xq = xq;
+    float *o = T.lk[lane];
+    o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
+    DM_SYNC();
+    Q4 pq = {1.f, 0.f, 0.f, 0.f};
+    if (parent >= 0) { const float *p = T.lk[parent]; pq = {p[3], p[4], p[5], p[6]}; }
+    const M3 Rp = q2m(pq);
+#pragma unroll
+    for (int s = 0; s < 3; s++) { axw[s] = mv(Rp, axp[s]); anc[s] = xp; }
     DM_SYNC();
   }
   BSTAMP(0);  // kinematics sweep
@@ -408,24 +423,43 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   S6 cdof[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) cdof[s] = s < ndof ? mk6(axw[s], cross(axw[s], c0 - anc[s])) : zero6();
-  // ---- mj: mj_comVel + the acceleration half of mj_rne, one level per sweep
-#pragma unroll 1
-  for (int d = 1; d <= M.maxdepth; d++) {
-    if (depth == d) {
-      S6 pv = zero6(), pa = {0.f, 0.f, 0.f, 0.f, 0.f, (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz};
-      if (parent >= 0) { const float *p = T.lk[parent]; pv = ld6(p); pa = ld6(p + 6); }
+  // ---- mj: mj_comVel + the acceleration half of mj_rne.  All motion vectors refer to the fixed thorax origin, so a link's
+  //      velocity is the plain sum of v * cdof over its ancestor path: path sums by pointer jumping (published inclusive,
+  //      the exclusive one - the parent's velocity - kept privately), the velocity products locally, then the same path
+  //      sum for the bias accelerations.
+  {
+    S6 dv = zero6();
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
-        if (s < ndof) {
-          const S6 cdd = cross_motion(pv, cdof[s]);
-          pv = pv + c.v[s] * cdof[s];
-          pa = pa + c.v[s] * cdd;
-        }
-      }
-      c.cvel = pv; c.caccb = pa;
-      st6(T.lk[lane], pv); st6(T.lk[lane] + 6, pa);
+    for (int s = 0; s < 3; s++) if (s < ndof) dv = dv + c.v[s] * cdof[s];
+    S6 sv = dv, pv = zero6();
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int a = r == 0 ? parent : (r == 1 ? anc2 : anc4);
+      st6(T.lk[lane], sv);
+      DM_SYNC();
+      if (a >= 0) { const S6 t = ld6(T.lk[a]); sv = sv + t; pv = pv + t; }
+      DM_SYNC();
     }
-    DM_SYNC();
+    S6 da = zero6();
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      if (s < ndof) {
+        const S6 cdd = cross_motion(pv, cdof[s]);
+        pv = pv + c.v[s] * cdof[s];
+        da = da + c.v[s] * cdd;
+      }
+    }
+    c.cvel = pv;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int a = r == 0 ? parent : (r == 1 ? anc2 : anc4);
+      st6(T.lk[lane], da);
+      DM_SYNC();
+      if (a >= 0) da = da + ld6(T.lk[a]);
+      DM_SYNC();
+    }
+    da.l2 += (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz;
+    c.caccb = da;
   }
   BSTAMP(1);  // velocity sweep
   // ---- body forces: rigid-body bias (mj_rne) minus inertia-box drag (mj_inertiaBoxFluidModel), about c0
@@ -446,27 +480,20 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     }
   }
   // ---- subtree sums (mj_crb's composite inertia, then mj_rne's backward pass), leaves first
+  //      Links are numbered depth first, so the subtree of link l is lanes l .. l + sub - 1: every lane gathers its own
+  //      range from one publication of the per-link values (no level order, no barrier inside the loop).
   I10 crb = cinert;
+  const int maxsub = M.maxsub;
+  st10(T.lk[lane], cinert);
+  DM_SYNC();
 #pragma unroll 1
-  for (int d = M.maxdepth; d >= 1; d--) {
-    if (depth == d) {
-      if (nchild > 0) crb = add10(crb, ld10(T.lk[ch0]));
-      if (nchild > 1) crb = add10(crb, ld10(T.lk[ch1]));
-      if (nchild > 2) crb = add10(crb, ld10(T.lk[ch2]));
-      st10(T.lk[lane], crb);
-    }
-    DM_SYNC();
-  }
+  for (int t = 1; t < maxsub; t++) if (t < sub) crb = add10(crb, ld10(T.lk[lane + t]));
+  DM_SYNC();
+  st6(T.lk[lane], ftot);
+  DM_SYNC();
 #pragma unroll 1
-  for (int d = M.maxdepth; d >= 1; d--) {
-    if (depth == d) {
-      if (nchild > 0) ftot = ftot + ld6(T.lk[ch0]);
-      if (nchild > 1) ftot = ftot + ld6(T.lk[ch1]);
-      if (nchild > 2) ftot = ftot + ld6(T.lk[ch2]);
-      st6(T.lk[lane], ftot);
-    }
-    DM_SYNC();
-  }
+  for (int t = 1; t < maxsub; t++) if (t < sub) ftot = ftot + ld6(T.lk[lane + t]);
+  DM_SYNC();
   BSTAMP(2);  // body forces + subtree sweep
   // ---- smooth joint forces without actuation: springs, dampers, -(bias - drag)
 #pragma unroll
@@ -1171,8 +1198,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   //      force on the tarsus from its parent, in the tarsus site frame.  Only the linear part of the spatial force is
   //      needed: m (a_lin + alpha x r + w x (v_lin + w x r)) with r = CoM - origin.
   {
-    const int depth = l_depth(c), parent = l_parent(c), ndof = l_ndof(c);
-    const int nchild = (int)(c.lkids >> 24), ch0 = (int)(c.lkids & 0xffu), ch1 = (int)((c.lkids >> 8) & 0xffu), ch2 = (int)((c.lkids >> 16) & 0xffu);
+    const int parent = l_parent(c), ndof = l_ndof(c);
+    const unsigned tree = M.l_tree[lane];
+    const int sub = (int)(tree & 0xffu), anc2 = (int)((tree >> 8) & 0xffu) - 1, anc4 = (int)((tree >> 16) & 0xffu) - 1;
     V3 fext = {0.f, 0.f, 0.f};
     float touch = 0.f;
     for (int k = 0; k < nc; k++) {
@@ -1183,32 +1211,28 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         if (f0 > 0.f) touch += f0;
       }
     }
-    S6 dacc = zero6();  // sum over the ancestors' dofs of cdof * qacc
-#pragma unroll 1
-    for (int d = 1; d <= M.maxdepth; d++) {
-      if (depth == d) {
-        S6 pa = zero6();
-        if (parent >= 0) pa = ld6(T.lk[parent]);
+    S6 dacc = zero6();  // sum over the dofs of the ancestor path of cdof * qacc (path sum by pointer jumping, as in stage 1)
 #pragma unroll
-        for (int s = 0; s < 3; s++) if (s < ndof) pa = pa + a[s] * ld6(T.C[opq(c.sdof[s])]);
-        dacc = pa;
-        st6(T.lk[lane], pa);
-      }
+    for (int s = 0; s < 3; s++) if (s < ndof) dacc = dacc + a[s] * ld6(T.C[opq(c.sdof[s])]);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int an = r == 0 ? parent : (r == 1 ? anc2 : anc4);
+      st6(T.lk[lane], dacc);
+      DM_SYNC();
+      if (an >= 0) dacc = dacc + ld6(T.lk[an]);
       DM_SYNC();
     }
     const S6 cacc = c.caccb + dacc;
     const V3 r = c.xip - V3{M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
     const V3 w = ang(c.cvel);
     V3 fint = c.mass * (lin(cacc) + cross(ang(cacc), r) + cross(w, lin(c.cvel) + cross(w, r))) - fext;
+    {  // subtree sum over the link's depth-first lane range
+      float *o = T.lk[lane];
+      o[0] = fint.x; o[1] = fint.y; o[2] = fint.z;
+      DM_SYNC();
+      const int maxsub = M.maxsub;
 #pragma unroll 1
-    for (int d = M.maxdepth; d >= 1; d--) {
-      if (depth == d) {
-        if (nchild > 0) { const float *p = T.lk[ch0]; fint = fint + V3{p[0], p[1], p[2]}; }
-        if (nchild > 1) { const float *p = T.lk[ch1]; fint = fint + V3{p[0], p[1], p[2]}; }
-        if (nchild > 2) { const float *p = T.lk[ch2]; fint = fint + V3{p[0], p[1], p[2]}; }
-        float *o = T.lk[lane];
-        o[0] = fint.x; o[1] = fint.y; o[2] = fint.z;
-      }
+      for (int t = 1; t < maxsub; t++) if (t < sub) { const float *p = T.lk[lane + t]; fint = fint + V3{p[0], p[1], p[2]}; }
       DM_SYNC();
     }
     const int fi = M.l_force[lane], ti = M.l_touch[lane];
@@ -1254,7 +1278,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   c.st_t0 = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < 24; k++) c.st_acc[k] = 0;
 #endif
-  c.lpack = M.l_pack[lane]; c.lkids = M.l_kids[lane]; c.xh = M.x_on[lane];
+  c.lpack = M.l_pack[lane]; c.xh = M.x_on[lane];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
     const int f = M.s_dof[s][lane];

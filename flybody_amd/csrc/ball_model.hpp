@@ -101,6 +101,9 @@ struct BallModel {
   int noslip_iterations;
   float j_solimp[5], c_solimp[5];  // joint-limit / ball-contact impedance parameters (uniform over the model; checked on the host)
   unsigned l_pack[NL], l_kids[NL];  // parent+1 | depth << 8 | ndof << 12 ;  child0 | child1 << 8 | child2 << 16 | nchild << 24
+  unsigned l_tree[NL];              // subtree size (links are in depth-first order: the subtree of l is lanes l .. l + size - 1)
+                                    // | (ancestor 2 levels up) + 1 << 8 | (ancestor 4 levels up) + 1 << 16
+  int maxsub;                       // largest subtree size
 };
 
 namespace detail {
@@ -510,7 +513,19 @@ inline BallHost build_ball_model(const Blob &b) {
       else if (M.c_solimp[k] != M.g_solimp[k][l]) throw std::runtime_error("ball model: contact solimp is expected to be uniform");
     }
   }
+  M.maxsub = 1;
   for (int l = 0; l < NL; l++) {
+    auto up = [&](int x, int n) { for (int k = 0; k < n && x >= 0; k++) x = M.l_parent[x]; return x; };
+    int size = 1;  // depth-first numbering: the subtree is the run of following links that are deeper than l
+    while (l + size < NL && M.l_body[l + size] > 0 && M.l_depth[l + size] > M.l_depth[l]) size++;
+    for (int k = l + 1; k < NL; k++) {  // check: exactly the links of that run have l among their ancestors
+      bool desc = false;
+      for (int x = M.l_parent[k]; x >= 0; x = M.l_parent[x]) desc |= (x == l);
+      if (M.l_body[l] > 0 && M.l_body[k] > 0 && desc != (k < l + size)) throw std::runtime_error("ball model: links are not in depth-first order");
+    }
+    if (M.l_body[l] <= 0) size = 1;
+    M.maxsub = std::max(M.maxsub, size);
+    M.l_tree[l] = (unsigned)size | ((unsigned)(up(l, 2) + 1) << 8) | ((unsigned)(up(l, 4) + 1) << 16);
     M.l_pack[l] = (unsigned)(M.l_parent[l] + 1) | ((unsigned)M.l_depth[l] << 8) | ((unsigned)M.l_ndof[l] << 12);
     M.l_kids[l] = (unsigned)M.l_child[0][l] | ((unsigned)M.l_child[1][l] << 8) | ((unsigned)M.l_child[2][l] << 16) | ((unsigned)M.l_nchild[l] << 24);
   }
