@@ -1144,7 +1144,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     for (int k = 0; k < nc; k++) nact_ += T.c_excl[k] ? 0 : 1;
     const int nslip = (nact_ > 0 && !(c.flags & BF_NO_NOSLIP)) ? M.noslip_iterations : 0;
     ModelPtr mp_ = (ModelPtr)c.M;
-    if (R <= 16) iters = dense_newton<16>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    if (R <= 12) iters = dense_newton<12>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    else if (R <= 16) iters = dense_newton<16>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    else if (R <= 20) iters = dense_newton<20>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
     else if (R <= 24) iters = dense_newton<24>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
     else iters = dense_newton<RMAX>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
     BSTAMP(9);  // newton + noslip (dense, in registers)
