@@ -696,7 +696,9 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
     float L0 = 0.f, L1 = 0.f, L2 = 0.f;  // this row of the block-lower Cholesky factor of W: L[row][first .. first+2]
     auto eval = [&](float y, bool want_L) {
       // a contact's three rows are evaluated on all three lanes (the residuals come by shifts inside the block)
-      const float ya = __shfl(y, lane - sub), yb = __shfl(y, lane - sub + 1), yc = __shfl(y, lane - sub + 2);
+      // (by DPP wave shifts: no LDS round trip in the line search's inner evaluation)
+      const float u1 = wshl1(y), u2 = wshl1(u1), d1 = wshr1(y), d2 = wshr1(d1);
+      const float ya = sub == 0 ? y : (sub == 1 ? d1 : d2), yb = sub == 0 ? u1 : (sub == 1 ? y : d1), yc = sub == 0 ? u2 : (sub == 1 ? u1 : y);
       float f = 0.f;
       if (want_L) L0 = L1 = L2 = 0.f;
       if (crow) {
