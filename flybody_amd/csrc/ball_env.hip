@@ -722,10 +722,10 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
       return f;
     };
     bool fresh = false;  // yv, fv belong to the current lam
+    yv = y0v + gdot(lam);
 #pragma unroll 1
     for (int it = 0; it < kMaxNewton; it++) {
       fresh = true;
-      yv = y0v + gdot(lam);
       fv = eval(yv, true);
       const float ev = lam - fv;
       const float pv = gdot(ev);
@@ -805,16 +805,16 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
       }
       if (lane >= R) dl = 0.f;
       const float jdv = gdot(dl);
-      const float c0s = wave_sum(lane < R ? lam * jdv : 0.f), c1s = wave_sum(lane < R ? dl * jdv : 0.f);
-      // exact line search on the convex phi(alpha): root of phi'(alpha) = c0 + alpha c1 - sum_rows f(y + alpha jd) jd
+      const float c1s = wave_sum(lane < R ? dl * jdv : 0.f);
+      const float d0 = wave_sum(lane < R ? ev * jdv : 0.f);  // phi'(0) = (lambda - f(y)) . G d: the forces at y are already known
+      // exact line search on the convex phi(alpha): root of phi'(alpha) = phi'(0) + alpha c1 - sum_rows (f(y + alpha jd) - f(y)) jd
       auto dphi = [&](float al) {
         const float fa = eval(yv + al * jdv, false);
-        float acc = lane < R ? -fa * jdv : 0.f;
-        return c0s + al * c1s + wave_sum(acc);
+        float acc = lane < R ? (fv - fa) * jdv : 0.f;
+        return d0 + al * c1s + wave_sum(acc);
       };
       float alpha = 0.f;
       {
-        const float d0 = c0s - wave_sum(lane < R ? fv * jdv : 0.f);  // phi'(0): the forces at y are already known
         if (!(d0 < 0.f)) break;  // not a descent direction any more: converged to rounding
         float lo = 0.f, hi = 1.f, dlo = d0, dhi = dphi(1.f);
         int guard = 0;
@@ -834,13 +834,11 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
         }
       }
       lam += alpha * dl;
+      yv += alpha * jdv;  // y = y0 + G lambda stays current without another product
       fresh = false;
     }
     // forces at the solution
-    if (!fresh) {
-      yv = y0v + gdot(lam);
-      fv = eval(yv, false);
-    }
+    if (!fresh) fv = eval(yv, false);
     // ---- mj: mj_solNoSlip (ref: fruitfly.xml:4 noslip_iterations="3"): Gauss-Seidel on the tangential rows with the
     //      unregularised A = J M^-1 J' - which is G - normal and limit forces held fixed; res = G f + (J a_s - aref).
     //      G is symmetric, so row r of G against f is a wave sum over the lanes' column-r entries.
