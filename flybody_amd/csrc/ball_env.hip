@@ -373,7 +373,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     axp[s] = qrot(qrel, axis[s]);
     if (s < ndof) {
       float sn, cs;
-      sincosf(0.5f * c.q[s], &sn, &cs);
+      fsincos(0.5f * c.q[s], &sn, &cs);
       qrel = qmul(qrel, Q4{cs, axis[s].x * sn, axis[s].y * sn, axis[s].z * sn});
     }
   }
@@ -508,7 +508,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   }
   if (c.xh) {  // halteres: closed form (see ball_model.hpp)
     float sn, cs;
-    sincosf(c.q[2], &sn, &cs);
+    fsincos(c.q[2], &sn, &cs);
     float f = 0.f;
     if (!(c.flags & BF_NO_SPRING)) f -= M.s_stiff[2][lane] * (c.q[2] - M.s_sref[2][lane]);
     if (!(c.flags & BF_NO_DAMPER)) f -= M.s_damp[2][lane] * c.v[2];

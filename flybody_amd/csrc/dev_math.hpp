@@ -40,9 +40,25 @@ __device__ __forceinline__ V3 mtv(const M3 &m, V3 v) {
   return {m.m0 * v.x + m.m3 * v.y + m.m6 * v.z, m.m1 * v.x + m.m4 * v.y + m.m7 * v.z, m.m2 * v.x + m.m5 * v.y + m.m8 * v.z};
 }
 __device__ __forceinline__ V3 qrot(Q4 q, V3 v) { return mv(q2m(q), v); }
+// sin and cos together for |x| up to a few hundred radians (joint half angles are a few radians): Cody-Waite reduction by
+// pi/2 in three parts + the classic single-precision minimax polynomials on [-pi/4, pi/4]; max error 9e-8 (1.5 ulp at 1),
+// about a third of the instructions of the library routine, whose large-argument path is never needed here.
+__device__ __forceinline__ void fsincos(float x, float *sn, float *cs) {
+  const float k = rintf(x * 0.6366197723675814f);
+  float r = fmaf(-k, 1.5707855224609375f, x);
+  r = fmaf(-k, 1.0804334124e-05f, r);
+  r = fmaf(-k, 6.0770999344e-11f, r);
+  const float r2 = r * r;
+  const float s = fmaf(r * r2, fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r);
+  const float c = fmaf(r2 * r2, fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f), fmaf(-0.5f, r2, 1.f));
+  const int q = (int)k & 3;
+  const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
 __device__ __forceinline__ Q4 axis_angle(V3 ax, float ang) {
   float s, c;
-  sincosf(0.5f * ang, &s, &c);
+  fsincos(0.5f * ang, &s, &c);
   return {c, ax.x * s, ax.y * s, ax.z * s};
 }
 __device__ __forceinline__ S6 operator+(S6 a, S6 b) { return {a.a0 + b.a0, a.a1 + b.a1, a.a2 + b.a2, a.l0 + b.l0, a.l1 + b.l1, a.l2 + b.l2}; }
