@@ -679,18 +679,24 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
                                          const int have_ws) {
   BTile &T = *Tp;
   int iters = 0;
-    float Gr[RB], Sr[RB];
+    // The row arrays are kept as float pairs so that the broadcast-multiply-accumulate loops (products with G, the Cholesky
+    // updates) issue as v_pk_fma_f32 with the two v_readlane results as an SGPR pair: 3 instructions per 2 columns, not 4.
+    f2 Gp[RB / 2], Sp[RB / 2];
+    auto G_ = [&](int j) -> float { return (j & 1) ? Gp[j >> 1].y : Gp[j >> 1].x; };
+    auto S_ = [&](int j) -> float { return (j & 1) ? Sp[j >> 1].y : Sp[j >> 1].x; };
+    auto setS = [&](int j, float v) { if (j & 1) Sp[j >> 1].y = v; else Sp[j >> 1].x = v; };
+    auto gload = [&](int j) -> float { return (lane < R && j < R) ? T.G[j <= lane ? lane * (lane + 1) / 2 + j : j * (j + 1) / 2 + lane] : 0.f; };
 #pragma unroll
-    for (int j = 0; j < RB; j++) Gr[j] = (lane < R && j < R) ? T.G[j <= lane ? lane * (lane + 1) / 2 + j : j * (j + 1) / 2 + lane] : 0.f;
+    for (int m = 0; m < RB / 2; m++) Gp[m] = f2{gload(2 * m), gload(2 * m + 1)};
     float lam = lane < R ? T.r_lam[lane] : 0.f;
     const float y0v = lane < R ? T.r_y0[lane] : 0.f;
     const bool crow = lane < nrc;           // contact row (else limit row or idle lane)
     const int sub = crow ? lane % 3 : 0;    // position inside the contact's 3-row block
     auto gdot = [&](float vreg) {           // (G v)[lane], v given as one value per lane
-      float acc = 0.f;
+      f2 acc = f2{0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < RB; j++) acc += Gr[j] * rl_f(vreg, j);  // Gr[j] = 0 beyond the R live rows
-      return acc;
+      for (int m = 0; m < RB / 2; m++) acc = __builtin_elementwise_fma(Gp[m], f2{rl_f(vreg, 2 * m), rl_f(vreg, 2 * m + 1)}, acc);  // G = 0 beyond the R live rows
+      return acc.x + acc.y;
     };
     float fv = 0.f, yv = 0.f;
     float L0 = 0.f, L1 = 0.f, L2 = 0.f;  // this row of the block-lower Cholesky factor of W: L[row][first .. first+2]
@@ -748,13 +754,13 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
         if (j < nrc) {
           const int fj = j - j % 3, sj = j % 3;
           // L[fj + b][j] for b = sj .. 2: lane fj+b holds it at position sj
-          tj = Gr[j] * rl_f(sj == 0 ? L0 : (sj == 1 ? L1 : L2), j);
-          if (sj < 2) tj += Gr[fj + sj + 1 < RB ? fj + sj + 1 : 0] * rl_f(sj == 0 ? L0 : L1, fj + sj + 1 < RB ? fj + sj + 1 : 0);
-          if (sj < 1) tj += Gr[fj + 2 < RB ? fj + 2 : 0] * rl_f(L0, fj + 2 < RB ? fj + 2 : 0);
-        } else tj = Gr[j] * rl_f(L0, j);
+          tj = G_(j) * rl_f(sj == 0 ? L0 : (sj == 1 ? L1 : L2), j);
+          if (sj < 2) tj += G_(fj + sj + 1 < RB ? fj + sj + 1 : 0) * rl_f(sj == 0 ? L0 : L1, fj + sj + 1 < RB ? fj + sj + 1 : 0);
+          if (sj < 1) tj += G_(fj + 2 < RB ? fj + 2 : 0) * rl_f(L0, fj + 2 < RB ? fj + 2 : 0);
+        } else tj = G_(j) * rl_f(L0, j);
         const float t1 = wshl1(tj), t2 = wshl1(t1);
-        Sr[j] = (j == lane ? 1.f : 0.f) + Ld * tj + La1 * t1 + La2 * t2;
-        } else Sr[j] = j == lane ? 1.f : 0.f;
+        setS(j, (j == lane ? 1.f : 0.f) + Ld * tj + La1 * t1 + La2 * t2);
+        } else setS(j, j == lane ? 1.f : 0.f);
       }
       // rhs = L' p
       float w;
@@ -768,35 +774,38 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
 #pragma unroll
       for (int k = 0; k < RB; k++) {
         if (k < R) {
-          const float ip = __builtin_amdgcn_rsqf(rl_f(Sr[k], k));
-          const float lik = Sr[k] * ip;
+          const float ip = __builtin_amdgcn_rsqf(rl_f(S_(k), k));
+          const float lik = S_(k) * ip;
+          if ((k & 1) == 0) Sp[k >> 1].y -= lik * rl_f(lik, k + 1);  // the pair partner of an even pivot column
+          const f2 nl = f2{-lik, -lik};
 #pragma unroll
-          for (int j = k + 1; j < RB; j++) Sr[j] -= lik * rl_f(lik, j);  // rows / columns beyond R are identity: no-ops
-          Sr[k] = lane > k ? lik * ip : 0.f;
+          for (int m = (k >> 1) + 1; m < RB / 2; m++)  // rows / columns beyond R are identity: no-ops
+            Sp[m] = __builtin_elementwise_fma(nl, f2{rl_f(lik, 2 * m), rl_f(lik, 2 * m + 1)}, Sp[m]);
+          setS(k, lane > k ? lik * ip : 0.f);
           ipp = lane == k ? ip * ip : ipp;
         }
       }
       // forward substitution Lt z = w
 #pragma unroll
       for (int k = 0; k < RB; k++)
-        if (k < R) w -= Sr[k] * rl_f(w, k);
+        if (k < R) w -= S_(k) * rl_f(w, k);
       w *= ipp;
       // transpose through LDS (this lane's column of Lt), then backward substitution Lt' u = D^-1 z
       if (lane < R) {
 #pragma unroll
-        for (int j = 0; j < RB; j++) if (j < R) T.S[lane][j] = Sr[j];
+        for (int j = 0; j < RB; j++) if (j < R) T.S[lane][j] = S_(j);
       }
       DM_SYNC();
 #pragma unroll
-      for (int k = 0; k < RB; k++) Sr[k] = 0.f;
+      for (int m = 0; m < RB / 2; m++) Sp[m] = f2{0.f, 0.f};
       if (lane < R) {
 #pragma unroll
-        for (int k = 0; k < RB; k++) if (k < R) Sr[k] = T.S[k][lane];
+        for (int k = 0; k < RB; k++) if (k < R) setS(k, T.S[k][lane]);
       }
       DM_SYNC();
 #pragma unroll
       for (int k = RB - 1; k >= 0; k--)
-        if (k < R) w -= Sr[k] * rl_f(w, k);
+        if (k < R) w -= S_(k) * rl_f(w, k);
       // d = -e + L u, jd = G d
       float dl;
       {
@@ -855,7 +864,7 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
             const int r0 = 3 * k + 1, r1 = 3 * k + 2;
             const float res0 = rl_f(res, r0), res1 = rl_f(res, r1);
             const float o0 = rl_f(fv, r0), o1 = rl_f(fv, r1), fn = rl_f(fv, 3 * k);
-            const float A00 = rl_f(Gr[r0], r0), A01 = rl_f(Gr[r1], r0), A11 = rl_f(Gr[r1], r1);
+            const float A00 = rl_f(G_(r0), r0), A01 = rl_f(G_(r1), r0), A11 = rl_f(G_(r1), r1);
             float v0 = 0.f, v1 = 0.f;
             if (fn >= 1e-15f) {
               const float b0 = res0 - A00 * o0 - A01 * o1, b1 = res1 - A01 * o0 - A11 * o1, mu = T.c_mu[k];
@@ -874,7 +883,7 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
             if (change > 1e-10f + 1e-4f * (fabsf(lin_) + fabsf(quad_))) { v0 = o0; v1 = o1; d0 = d1 = 0.f; change = 0.f; }
             improvement -= fminf(change, 0.f);
             fv = lane == r0 ? v0 : (lane == r1 ? v1 : fv);
-            res += Gr[r0] * d0 + Gr[r1] * d1;
+            res += G_(r0) * d0 + G_(r1) * d1;
           }
         }
         if (improvement * scale < 1e-6f) break;

@@ -8,6 +8,7 @@ namespace dm {
 struct V3 { float x, y, z; };
 struct Q4 { float w, x, y, z; };
 struct S6 { float a0, a1, a2, l0, l1, l2; };
+typedef float f2 __attribute__((ext_vector_type(2)));  // register pair for v_pk_* arithmetic
 struct M3 { float m0, m1, m2, m3, m4, m5, m6, m7, m8; };
 struct I10 { float i0, i1, i2, i3, i4, i5, i6, i7, i8, i9; };
 
