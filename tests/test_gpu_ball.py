@@ -274,3 +274,38 @@ def test_config1_single_env_1000_random_steps(torch_mod):
     ints, _ = env.get_task_state()
     assert int(ints[0, 7]) == 0  # no contact overflow
     env.close()
+
+
+def test_full_episode_soak_batch_1024(torch_mod):
+    """A whole 2.0 s episode (1000 control steps = 10 000 contact-solving substeps) of 1024 envs under random actions, across
+    the time-limit reset: every observation finite, rewards in [0, 1], all envs reach LAST together at step 1000 and FIRST on
+    the next call, contact counts within capacity, and the capacity-overflow flag (column 7 of the task state) never raised."""
+    from flybody_amd import fly_envs
+
+    torch = torch_mod
+    B = 1024
+    env = fly_envs.walk_on_ball(batch_size=B)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = [(torch.rand(B, 59, device="cuda", generator=g) * 0.4 - 0.2).contiguous() for _ in range(32)]
+    rsum = torch.zeros(B, device="cuda")
+    finite = torch.ones((), dtype=torch.bool, device="cuda")
+    overflow = torch.zeros(B, dtype=torch.int32, device="cuda")
+    maxcon = torch.zeros(B, dtype=torch.int32, device="cuda")
+    for k in range(1000):
+        ts = env.step(acts[k % 32])
+        rsum += ts.reward
+        finite &= torch.isfinite(env.flat_observation).all() & torch.isfinite(ts.reward).all()
+        if k % 50 == 49 or k == 999:
+            ints, _ = env.get_task_state()
+            overflow |= ints[:, 7]
+            maxcon = torch.maximum(maxcon, ints[:, 5])
+    assert bool(finite)
+    assert (ts.step_type == 2).all() and (ts.discount == 1.0).all()
+    assert float(rsum.min()) >= 0.0 and float(rsum.max()) <= 1000.0 and 0.0 < float(rsum.mean()) / 1000 < 1.0
+    assert int(overflow.max()) == 0, f"{int((overflow != 0).sum())} envs overflowed the contact / row capacity"
+    assert 1 <= int(maxcon.max()) <= 10
+    ts = env.step(acts[0])
+    assert (ts.step_type == 0).all()
+    print(f"soak: mean reward {float(rsum.mean()) / 1000:.4f}, max contacts seen {int(maxcon.max())}")
+    env.close()
