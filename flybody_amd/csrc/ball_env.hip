@@ -3,12 +3,13 @@
 // ONE 64-lane wavefront per environment, one launch = one control step (10 physics substeps of 2e-4 s, dm_control's
 // legacy mj_step2;mj_step1 order, buffered sensors, observation, reward, termination, auto-reset).  Lane mapping and
 // the model tables are described in ball_model.hpp.  Per substep (mj: mj_step restated):
-//   stage 1  kinematics (level sweep), spatial inertias about the fixed thorax origin, velocities / bias accelerations
-//            (level sweep), inertia-box drag, composite inertias and subtree forces (level sweep), joint-space inertia
-//            (582 entries across the lanes) and its block factorisation, ball-capsule collision;
+//   stage 1  kinematics, velocities / bias accelerations (root-to-leaf passes by pointer jumping), spatial inertias about the
+//            fixed thorax origin, inertia-box drag, composite inertias and subtree forces (gathers over depth-first lane
+//            ranges), joint-space inertia (582 entries across the lanes), block factorisation of M and M + hB together,
+//            ball-capsule collision;
 //   stage 2  filtered actuators (+ adhesion through the contact normals), smooth acceleration, joint-limit and
-//            elliptic-cone contact rows, Newton iterations on the convex constraint cost (exact Hessian; the ball's
-//            3 dofs are eliminated through a Schur complement so the fly part keeps M's block sparsity), noslip sweeps,
+//            elliptic-cone contact rows, the constraint solve in the space of those rows (G = J M^-1 J' from block solves,
+//            dense Newton with the exact cone Hessian in registers, lane = row), noslip sweeps on the same G,
 //            touch / force sensors, implicit-in-damping Euler integration.
 // Parity tests: tests/test_gpu_ball.py.
 #include <hip/hip_runtime.h>
@@ -73,7 +74,7 @@ struct alignas(16) BTile {
   float C[NDP][6];
   union {
     float F[NDP][6];           // crb * cdof during the inertia assembly
-    float lk[NL][12];          // link exchange of the level sweeps: pose (7) | velocity + acceleration (12) | crb (10) | force (6)
+    float lk[NL][12];          // link exchange of the tree passes: pose (7) | motion vector (6) | crb (10) | force (6)
     float G[RMAX * (RMAX + 1) / 2];  // stage 2: G = J M^-1 J' over the constraint rows, lower triangle packed by rows (lane r owns row r)
   };
   float frc[64];
@@ -364,7 +365,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
 #pragma unroll
   for (int s = 0; s < 3; s++) axis[s] = {M.s_axis[0][s][lane], M.s_axis[1][s][lane], M.s_axis[2][s][lane]};
   // Every joint of this model sits at its body's origin (checked on the host), so a link's origin does not depend on
-  // its own joint angles and everything that does not involve the parent is done once, outside the level sweep:
+  // its own joint angles and everything that does not involve the parent is done once, before the tree pass:
   // the link's orientation relative to its parent after 0, 1, 2, 3 of its joints and the joint axes in the parent frame.
   Q4 qrel = quat;
   V3 axp[3];
@@ -413,7 +414,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     for (int s = 0; s < 3; s++) { axw[s] = mv(Rp, axp[s]); anc[s] = xp; }
     DM_SYNC();
   }
-  BSTAMP(0);  // kinematics sweep
+  BSTAMP(0);  // kinematics
   const M3 xmat = q2m(c.xq);
   c.xip = c.xp + mv(xmat, V3{M.l_ipos[0][lane], M.l_ipos[1][lane], M.l_ipos[2][lane]});
   const M3 ximat = q2m(qmul(c.xq, Q4{M.l_iquat[0][lane], M.l_iquat[1][lane], M.l_iquat[2][lane], M.l_iquat[3][lane]}));
@@ -461,7 +462,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     da.l2 += (c.flags & BF_NO_GRAVITY) ? 0.f : -M.gz;
     c.caccb = da;
   }
-  BSTAMP(1);  // velocity sweep
+  BSTAMP(1);  // velocities + bias accelerations
   // ---- body forces: rigid-body bias (mj_rne) minus inertia-box drag (mj_inertiaBoxFluidModel), about c0
   S6 ftot;
   {
@@ -494,7 +495,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
 #pragma unroll 1
   for (int t = 1; t < maxsub; t++) if (t < sub) ftot = ftot + ld6(T.lk[lane + t]);
   DM_SYNC();
-  BSTAMP(2);  // body forces + subtree sweep
+  BSTAMP(2);  // body forces + subtree sums
   // ---- smooth joint forces without actuation: springs, dampers, -(bias - drag)
 #pragma unroll
   for (int s = 0; s < 3; s++) {
