@@ -1446,14 +1446,32 @@ __global__ __launch_bounds__(1024) void ball_order_kernel(const BState *__restri
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
   __syncthreads();
-  for (int e = t; e < batch; e += 1024) atomicAdd(&hist[min(255, max(0, states[e].iters))], 1);
-  __syncthreads();
-  if (t == 0) {
-    int acc = 0;
-    for (int k = 255; k >= 0; k--) { start[k] = acc; acc += hist[k]; }
+  constexpr int KPT = 8;  // keys kept in registers between the two passes (batches up to 8 192; larger ones re-read)
+  int key[KPT];
+#pragma unroll
+  for (int q = 0; q < KPT; q++) {
+    const int e = t + q * 1024;
+    key[q] = e < batch ? min(255, max(0, states[e].iters)) : -1;
+    if (key[q] >= 0) atomicAdd(&hist[key[q]], 1);
   }
+  for (int e = t + KPT * 1024; e < batch; e += 1024) atomicAdd(&hist[min(255, max(0, states[e].iters))], 1);
   __syncthreads();
-  for (int e = t; e < batch; e += 1024) order[atomicAdd(&start[min(255, max(0, states[e].iters))], 1)] = e;
+  // exclusive suffix sums (descending keys first): start[k] = number of envs with a key > k
+  if (t < 256) start[t] = hist[t];
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int v = 0;
+    if (t < 256 && t + off < 256) v = start[t + off];
+    __syncthreads();
+    if (t < 256) start[t] += v;
+    __syncthreads();
+  }
+  if (t < 256) start[t] -= hist[t];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < KPT; q++)
+    if (key[q] >= 0) order[atomicAdd(&start[key[q]], 1)] = t + q * 1024;
+  for (int e = t + KPT * 1024; e < batch; e += 1024) order[atomicAdd(&start[min(255, max(0, states[e].iters))], 1)] = e;
 }
 __global__ void ball_get_state_kernel(const BState *states, double *qpos, double *qvel, int batch) {
   const int env = blockIdx.x, t = threadIdx.x;
