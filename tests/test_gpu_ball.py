@@ -245,7 +245,7 @@ def test_config3_batch_rollout_properties(torch_mod):
     obs = env.flat_observation
     assert torch.isfinite(obs).all() and (ts.step_type == 1).all()
     ints, _ = env.get_task_state()
-    assert int(ints[:, 5].max()) <= 12 and int(ints[:, 5].min()) >= 1
+    assert int(ints[:, 5].max()) <= 10 and int(ints[:, 5].min()) >= 1
     r = ts.reward
     assert float(r.min()) >= 0.0 and float(r.max()) <= 1.0
     env.close()
