@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libflybody_env.so")
 SOURCES = ["fly_env.hip", "ball_env.hip"]
-HEADERS = ["dev_model.hpp", "ball_model.hpp", "ball_env.hpp", "dev_math.hpp", os.path.join("..", "..", "include", "flybody_env.h")]
+HEADERS = ["dev_model.hpp", "ball_model.hpp", "ball_env.hpp", "dev_math.hpp", "launch_order.hpp", os.path.join("..", "..", "include", "flybody_env.h")]
 
 
 def needs_build() -> bool:

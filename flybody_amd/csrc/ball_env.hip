@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "ball_env.hpp"
+#include "launch_order.hpp"
 #include "ball_model.hpp"
 #include "dev_math.hpp"
 
@@ -1284,8 +1285,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
                                                          const int *__restrict__ order) {
   // Workgroups are dispatched in index order; `order` lists the envs by decreasing cost of their previous control step, so the
   // expensive ones (more contacts, more Newton iterations) start first and the launch does not end on a few long waves
-  // running alone at low occupancy (walk_on_ball, B = 4 096: -3 % launch time).  Envs are independent: results do not
-  // depend on the order.
+  // running alone at low occupancy (launch_order.hpp; walk_on_ball, B = 4 096: -3 % launch time).
   if ((int)blockIdx.x >= batch) return;
   const int env = order[blockIdx.x], lane = threadIdx.x;
   __shared__ BTile T;
@@ -1439,40 +1439,9 @@ __global__ void ball_init_states(BState *states, int *order, int batch) {
   states[i] = z;
   order[i] = i;
 }
-// Counting sort of the envs by the solver work of their last control step (Newton iterations summed over its substeps, the
-// quantity the launch time varies with), most expensive first: one workgroup, ties in arbitrary order.
-__global__ __launch_bounds__(1024) void ball_order_kernel(const BState *__restrict__ states, int *__restrict__ order, int batch) {
-  __shared__ int hist[256], start[256];
-  const int t = threadIdx.x;
-  if (t < 256) hist[t] = 0;
-  __syncthreads();
-  constexpr int KPT = 8;  // keys kept in registers between the two passes (batches up to 8 192; larger ones re-read)
-  int key[KPT];
-#pragma unroll
-  for (int q = 0; q < KPT; q++) {
-    const int e = t + q * 1024;
-    key[q] = e < batch ? min(255, max(0, states[e].iters)) : -1;
-    if (key[q] >= 0) atomicAdd(&hist[key[q]], 1);
-  }
-  for (int e = t + KPT * 1024; e < batch; e += 1024) atomicAdd(&hist[min(255, max(0, states[e].iters))], 1);
-  __syncthreads();
-  // exclusive suffix sums (descending keys first): start[k] = number of envs with a key > k
-  if (t < 256) start[t] = hist[t];
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    int v = 0;
-    if (t < 256 && t + off < 256) v = start[t + off];
-    __syncthreads();
-    if (t < 256) start[t] += v;
-    __syncthreads();
-  }
-  if (t < 256) start[t] -= hist[t];
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < KPT; q++)
-    if (key[q] >= 0) order[atomicAdd(&start[key[q]], 1)] = t + q * 1024;
-  for (int e = t + KPT * 1024; e < batch; e += 1024) order[atomicAdd(&start[min(255, max(0, states[e].iters))], 1)] = e;
-}
+// cost key of the launch order (launch_order.hpp): Newton iterations summed over the substeps of the last control step, the
+// quantity the launch time varies with
+struct BallCostKey { __device__ int operator()(const BState &s) const { return s.iters; } };
 __global__ void ball_get_state_kernel(const BState *states, double *qpos, double *qvel, int batch) {
   const int env = blockIdx.x, t = threadIdx.x;
   if (env >= batch) return;
@@ -1516,7 +1485,7 @@ struct BallEnv {
   BTaskDev task{};
   BallModel *model_dev = nullptr;
   BState *states = nullptr;
-  int *order = nullptr;  // launch order of the envs (ball_order_kernel)
+  int *order = nullptr;  // launch order of the envs (launch_order.hpp)
   double control_timestep = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -1569,7 +1538,7 @@ void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *di
                      e->batch, mode, nphys, e->order);
   HIPB_OK(hipGetLastError());
   if (mode == 0 && e->batch > 1) {
-    hipLaunchKernelGGL(ball_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->states, e->order, e->batch);
+    hipLaunchKernelGGL((ffe_order::order_by_cost<BState, BallCostKey>), dim3(1), dim3(1024), 0, (hipStream_t)stream, e->states, e->order, e->batch, BallCostKey{});
     HIPB_OK(hipGetLastError());
   }
 }
