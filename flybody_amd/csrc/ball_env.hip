@@ -1282,7 +1282,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__restrict__ Mp, BTaskDev K, BState *__restrict__ states,
                                                          const float *__restrict__ act, float *__restrict__ obs, float *__restrict__ rew,
                                                          float *__restrict__ disc, int *__restrict__ st, int batch, int mode, int nphys,
-                                                         const int *__restrict__ order) {
+                                                         const int *__restrict__ order, int *__restrict__ cost) {
   // Workgroups are dispatched in index order; `order` lists the envs by decreasing cost of their previous control step, so the
   // expensive ones (more contacts, more Newton iterations) start first and the launch does not end on a few long waves
   // running alone at low occupancy (launch_order.hpp; walk_on_ball, B = 4 096: -3 % launch time).
@@ -1371,6 +1371,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
     S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc;
+    cost[env] = iters;  // key of the next launch's order: Newton iterations over this step's substeps, what the launch time varies with
     if (do_reset) S.overflow = 0; else if (c.overflow) S.overflow = 1;
     S.have_ws = do_reset ? 0 : c.have_ws;
   }
@@ -1430,7 +1431,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   }
 }
 
-__global__ void ball_init_states(BState *states, int *order, int batch) {
+__global__ void ball_init_states(BState *states, int *order, int *cost, int batch) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
   BState z;
@@ -1438,10 +1439,8 @@ __global__ void ball_init_states(BState *states, int *order, int batch) {
   z.needs_reset = 1; z.ballq[0] = 1.f;
   states[i] = z;
   order[i] = i;
+  cost[i] = 0;
 }
-// cost key of the launch order (launch_order.hpp): Newton iterations summed over the substeps of the last control step, the
-// quantity the launch time varies with
-struct BallCostKey { __device__ int operator()(const BState &s) const { return s.iters; } };
 __global__ void ball_get_state_kernel(const BState *states, double *qpos, double *qvel, int batch) {
   const int env = blockIdx.x, t = threadIdx.x;
   if (env >= batch) return;
@@ -1485,7 +1484,7 @@ struct BallEnv {
   BTaskDev task{};
   BallModel *model_dev = nullptr;
   BState *states = nullptr;
-  int *order = nullptr;  // launch order of the envs (launch_order.hpp)
+  int *order = nullptr, *cost = nullptr;  // launch order of the envs and its sort keys (launch_order.hpp)
   double control_timestep = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -1508,7 +1507,8 @@ BallEnv *ball_create(const void *blob, size_t blob_size, const BallTaskHost &tas
   HIPB_OK(hipMemcpy(e->model_dev, &e->host.m, sizeof(BallModel), hipMemcpyHostToDevice));
   HIPB_OK(hipMalloc((void **)&e->states, sizeof(BState) * (size_t)batch));
   HIPB_OK(hipMalloc((void **)&e->order, sizeof(int) * (size_t)batch));
-  hipLaunchKernelGGL(ball_init_states, dim3((batch + 63) / 64), dim3(64), 0, 0, e->states, e->order, batch);
+  HIPB_OK(hipMalloc((void **)&e->cost, sizeof(int) * (size_t)batch));
+  hipLaunchKernelGGL(ball_init_states, dim3((batch + 63) / 64), dim3(64), 0, 0, e->states, e->order, e->cost, batch);
   HIPB_OK(hipGetLastError());
   HIPB_OK(hipDeviceSynchronize());
   HIPB_OK(hipEventCreate(&e->ev0));
@@ -1521,6 +1521,7 @@ void ball_destroy(BallEnv *e) {
   if (e->model_dev) (void)hipFree(e->model_dev);
   if (e->states) (void)hipFree(e->states);
   if (e->order) (void)hipFree(e->order);
+  if (e->cost) (void)hipFree(e->cost);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   delete e;
@@ -1535,10 +1536,10 @@ void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *di
   if (mode != 1 && !act) throw std::runtime_error("walk_on_ball: null action buffer");
   if (mode != 2 && (!obs || !rew || !disc || !st)) throw std::runtime_error("walk_on_ball: null output buffer");
   hipLaunchKernelGGL(ball_step_kernel, dim3(e->batch), dim3(64), 0, (hipStream_t)stream, e->model_dev, e->task, e->states, act, obs, rew, disc, st,
-                     e->batch, mode, nphys, e->order);
+                     e->batch, mode, nphys, e->order, e->cost);
   HIPB_OK(hipGetLastError());
   if (mode == 0 && e->batch > 1) {
-    hipLaunchKernelGGL((ffe_order::order_by_cost<BState, BallCostKey>), dim3(1), dim3(1024), 0, (hipStream_t)stream, e->states, e->order, e->batch, BallCostKey{});
+    hipLaunchKernelGGL(ffe_order::order_by_cost, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->cost, e->order, e->batch);
     HIPB_OK(hipGetLastError());
   }
 }

@@ -1148,7 +1148,7 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
 __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(const DevModel *__restrict__ Mp_, const TaskDev *__restrict__ Kp_, EnvState *__restrict__ states, const float *__restrict__ act,
                                                               float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                               float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode, int nphys,
-                                                              const int *__restrict__ order) {
+                                                              const int *__restrict__ order, int *__restrict__ cost) {
   __shared__ Tile T;
   const DevModel FFE_CONST *Mp = (const DevModel FFE_CONST *)Mp_;
   const TaskDev FFE_CONST *Kp = (const TaskDev FFE_CONST *)Kp_;
@@ -1351,6 +1351,9 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     S.wb_ctrl_freq = wb_cf; S.wb_step = wb_step; S.wb_freq_idx = wb_idx; S.step_counter = step_counter; S.traj_idx = traj_idx;
     S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.solver_iters = iters;
     S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
+    // key of the next launch's order: constraint-solver iterations of this step (0 while no joint limit is active), then the
+    // number of active limits
+    cost[env] = 8 * iters + min(7, S.nactive);
   }
   // carry the final stage-1 results to the next launch (a reset's single evaluation is that of the FIRST state)
   for (int e = lane; e < kMaxDof * 6; e += kWave) { S.s1_cdof[e] = (&T.cdof[0][0])[e]; S.s1_buf[e] = (&T.buf[0][0])[e]; }
@@ -1363,7 +1366,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
 #endif
 }
 
-__global__ void init_states_kernel(EnvState *states, int *order, int batch) {
+__global__ void init_states_kernel(EnvState *states, int *order, int *cost, int batch) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
   EnvState z;
@@ -1371,10 +1374,9 @@ __global__ void init_states_kernel(EnvState *states, int *order, int batch) {
   z.needs_reset = 1; z.forced_traj = -1;
   states[i] = z;
   order[i] = i;
+  cost[i] = 0;
 }
-// cost key of the launch order: constraint-solver iterations of the last control step (0 while no joint limit is active),
-// then the number of active limits
-struct FlightCostKey { __device__ int operator()(const EnvState &s) const { return 8 * s.solver_iters + min(7, s.nactive); } };
+
 __global__ void get_state_kernel(const EnvState *states, double *qpos, double *qvel, int batch, int nq, int nv) {
   int env = blockIdx.x, lane = threadIdx.x;
   if (env >= batch) return;
@@ -1433,7 +1435,7 @@ struct ffe_env {
   TaskDev *task_dev = nullptr;
   HostModel host;
   EnvState *states = nullptr;
-  int *order = nullptr;  // launch order of the envs (launch_order.hpp)
+  int *order = nullptr, *cost = nullptr;  // launch order of the envs and its sort keys (launch_order.hpp)
   unsigned char *arena = nullptr;
   std::vector<void *> allocs;
   std::string err;
@@ -1544,7 +1546,9 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
     h->allocs.push_back(h->states);
     HIP_OK(hipMalloc(reinterpret_cast<void **>(&h->order), sizeof(int) * (size_t)batch));
     h->allocs.push_back(h->order);
-    hipLaunchKernelGGL(init_states_kernel, dim3((batch + 255) / 256), dim3(256), 0, 0, h->states, h->order, batch);
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&h->cost), sizeof(int) * (size_t)batch));
+    h->allocs.push_back(h->cost);
+    hipLaunchKernelGGL(init_states_kernel, dim3((batch + 255) / 256), dim3(256), 0, 0, h->states, h->order, h->cost, batch);
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipEventCreate(&h->ev0));
@@ -1604,14 +1608,13 @@ static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, f
   FFE_BALL_DISPATCH(h, ffb::ball_launch(h->ball, act, obs, rew, disc, st, stream, mode, nphys));
   if (mode != 2 && (!obs || !rew || !disc || !st || (mode == 0 && !act))) { h->err = "null device buffer"; return -1; }
   hipLaunchKernelGGL(flight_step_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->dm_dev, h->task_dev, h->states, act, obs, rew,
-                     disc, st, h->batch, mode, nphys, h->order);
+                     disc, st, h->batch, mode, nphys, h->order, h->cost);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
-  // measured: +1 % env-steps/s at B = 4 096 / 8 192 (one or two rounds of the 4 096 resident waves); beyond that the tail the
-  // order shortens is a smaller share of the launch than the 8 us sort itself (-1 % at 16 384, -2 % at 32 768): not sorted
+  // measured: +2 % env-steps/s at B = 8 192 (two rounds of the 4 096 resident waves); beyond that the tail the order shortens
+  // is a smaller share of the launch than the serialised sort kernel itself (-1.5 % at 16 384, -2 % at 32 768): not sorted
   if (mode == 0 && h->batch > 1 && h->batch <= 8192) {
-    hipLaunchKernelGGL((ffe_order::order_by_cost<EnvState, FlightCostKey>), dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), h->states, h->order,
-                       h->batch, FlightCostKey{});
+    hipLaunchKernelGGL(ffe_order::order_by_cost, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), h->cost, h->order, h->batch);
     e = hipGetLastError();
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
   }

@@ -3,15 +3,15 @@
 // Workgroups are dispatched in index order and a launch ends when its slowest waves end, the last ones running alone at
 // low occupancy.  Envs differ in cost (active limits, contacts, solver iterations), and the cost of a control step predicts
 // the next one's, so each step launch is followed by a counting sort of the envs by that cost (one workgroup, keys 0..255,
-// descending, ties in arbitrary order); the step kernels read `env = order[blockIdx.x]`.  Envs are independent: results do
-// not depend on the order.
+// descending, ties in arbitrary order); the step kernels read `env = order[blockIdx.x]` and leave their cost in a compact
+// key array (`cost[env]`, read coalesced here).  Envs are independent: results do not depend on the order.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace ffe_order {
+namespace {  // one copy per translation unit
 
-template <class State, class KeyFn>
-__global__ __launch_bounds__(1024) void order_by_cost(const State *__restrict__ states, int *__restrict__ order, int batch, KeyFn keyfn) {
+__global__ __launch_bounds__(1024) void order_by_cost(const int *__restrict__ cost, int *__restrict__ order, int batch) {
   __shared__ int hist[256], start[256];
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
@@ -21,10 +21,10 @@ __global__ __launch_bounds__(1024) void order_by_cost(const State *__restrict__ 
 #pragma unroll
   for (int q = 0; q < KPT; q++) {
     const int e = t + q * 1024;
-    key[q] = e < batch ? min(255, max(0, keyfn(states[e]))) : -1;
+    key[q] = e < batch ? min(255, max(0, cost[e])) : -1;
     if (key[q] >= 0) atomicAdd(&hist[key[q]], 1);
   }
-  for (int e = t + KPT * 1024; e < batch; e += 1024) atomicAdd(&hist[min(255, max(0, keyfn(states[e])))], 1);
+  for (int e = t + KPT * 1024; e < batch; e += 1024) atomicAdd(&hist[min(255, max(0, cost[e]))], 1);
   __syncthreads();
   // exclusive suffix sums (descending keys first): start[k] = number of envs with a key > k
   if (t < 256) start[t] = hist[t];
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void order_by_cost(const State *__restrict__ 
 #pragma unroll
   for (int q = 0; q < KPT; q++)
     if (key[q] >= 0) order[atomicAdd(&start[key[q]], 1)] = t + q * 1024;
-  for (int e = t + KPT * 1024; e < batch; e += 1024) order[atomicAdd(&start[min(255, max(0, keyfn(states[e])))], 1)] = e;
+  for (int e = t + KPT * 1024; e < batch; e += 1024) order[atomicAdd(&start[min(255, max(0, cost[e]))], 1)] = e;
 }
 
+}  // namespace
 }  // namespace ffe_order
