@@ -309,3 +309,27 @@ def test_full_episode_soak_batch_1024(torch_mod):
     assert (ts.step_type == 0).all()
     print(f"soak: mean reward {float(rsum.mean()) / 1000:.4f}, max contacts seen {int(maxcon.max())}")
     env.close()
+
+
+def test_actor_loop_with_torch_policy(torch_mod):
+    """The caller of the hot path: a batched on-device policy driving walk_on_ball through
+    `BatchedActorLoop`; observations and actions never leave the GPU, episode statistics carry the reference's log keys."""
+    from flybody_amd import fly_envs
+    from flybody_amd.actor_loop import BatchedActorLoop
+
+    torch = torch_mod
+    B = 256
+    env = fly_envs.walk_on_ball(batch_size=B)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    W = 0.02 * torch.randn(289, 59, device="cuda", generator=g)
+    lo, hi = env.raw_action_bounds()
+    lo_t, hi_t = torch.tensor(lo, device="cuda"), torch.tensor(hi, device="cuda")
+
+    def policy(obs):
+        return torch.maximum(torch.minimum(torch.tanh(obs @ W) * 0.2, hi_t), lo_t)
+
+    loop = BatchedActorLoop(env, policy)
+    stats = loop.run(1001)  # one full 2.0 s episode of every env plus the first step of the next
+    assert stats["episodes"] == B and abs(stats["episode_length"] - 1000.0) < 1e-6
+    assert 0.0 <= stats["episode_return"] <= 1000.0 and stats["steps_per_second"] > 0
+    env.close()
