@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FLYBODY_ENV_LIB") or os.path.join(_HERE, "csrc", "libflybody_env.so")  # override: tuning variants only
 
 SYMBOLS = [
-    "ffe_create_flight", "ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step",
+    "ffe_create_flight", "ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_reset_envs", "ffe_step",
     "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps",
     "ffe_test_quat", "ffe_last_error", "ffe_version", "ffe_create_walk_on_ball", "ffe_get_act", "ffe_set_act",
 ]
@@ -22,7 +22,8 @@ class FlightTask(C.Structure):
         ("wb_traj", C.POINTER(C.c_double)), ("wb_phase", C.POINTER(C.c_double)),
         ("wb_base_freq", C.c_double), ("wb_rel_range", C.c_double), ("wb_rate", C.c_double), ("wb_dt_ctrl", C.c_double),
         ("ntraj", C.c_int32), ("traj_len", C.c_int32), ("ref_qpos", C.POINTER(C.c_double)), ("ref_qvel", C.POINTER(C.c_double)),
-        ("future_steps", C.c_int32), ("time_limit_steps", C.c_int32), ("terminal_com_dist", C.c_double),
+        ("traj_off", C.POINTER(C.c_int32)),
+        ("future_steps", C.c_int32), ("time_limit_steps", C.c_int32), ("episode_limit_steps", C.c_int32), ("terminal_com_dist", C.c_double),
         ("ghost_accel_z", C.c_double), ("pad_first_obs", C.c_int32), ("physics_flags", C.c_int32),
         ("canonical_actions", C.c_int32), ("clip_actions", C.c_int32),
     ]
@@ -75,10 +76,11 @@ def lib():
     L.ffe_spec.argtypes = [vp, C.POINTER(Spec)]
     L.ffe_action_bounds.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ffe_reset.argtypes = [vp, fp, fp, fp, ip, vp]
+    L.ffe_reset_envs.argtypes = [vp, vp, fp, fp, fp, ip, vp]
     L.ffe_step.argtypes = [vp, fp, fp, fp, fp, ip, vp]
     L.ffe_physics_step.argtypes = [vp, fp, C.c_int, vp]
     L.ffe_physics_step.restype = C.c_int
-    L.ffe_force_next_episode.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.ffe_force_next_episode.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double), vp]
     L.ffe_get_state.argtypes = [vp, dp, dp, vp]
     L.ffe_set_state.argtypes = [vp, dp, dp, vp]
     L.ffe_get_task_state.argtypes = [vp, ip, dp, vp]
@@ -87,7 +89,7 @@ def lib():
     L.ffe_last_error.restype = C.c_char_p
     L.ffe_last_error.argtypes = [vp]
     L.ffe_version.restype = C.c_char_p
-    for s in ("ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_step", "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state",
+    for s in ("ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_reset_envs", "ffe_step", "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state",
               "ffe_set_state", "ffe_get_task_state", "ffe_time_steps", "ffe_test_quat"):
         getattr(L, s).restype = C.c_int
     _lib = L

@@ -52,7 +52,8 @@ struct alignas(16) BState {
   float q[NDP], v[NDP], act[64];
   float ballq[4], ballw[4];
   float qacc_ws[NDP], wsc[NL][3];  // warm start of the constraint solver: last limit force per dof, last contact force per link
-  int step_counter, needs_reset, overflow, iters, ncon, have_ws, pad[2];
+  int step_counter, needs_reset, overflow, iters, ncon, have_ws;
+  unsigned con_hist[2];  // active (inside includemargin) contacts of each of the control step's first 16 substeps, 4 bits each: parity tooling
 };
 
 struct BTaskDev {
@@ -111,7 +112,7 @@ struct Ctx {
   float mass;
   Q4 bq;
   V3 bw, btau;
-  int nc;
+  int nc, nact;           // contacts detected / of those, the ones inside includemargin (they get constraint rows)
   float wsl[3], wsc[3];   // warm start of the constraint solver: last substep's limit force per slot, contact force of this link
   int have_ws, overflow;
 #ifdef FFB_STAMPS
@@ -572,6 +573,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   const unsigned long long bal = __ballot(hit);
   const int idx = __popcll(bal & ((1ull << lane) - 1ull));
   c.nc = min(__popcll(bal), NC);
+  c.nact = __popcll(__ballot(hit && idx < NC && !(dist >= margin - gap)));
   if (__popcll(bal) > NC) c.overflow = 1;  // more contacts than the tile holds: the extra ones are dropped and the env is flagged
   if (hit && idx < NC) {
     T.c_link[idx] = lane;
@@ -1282,12 +1284,17 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
 __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__restrict__ Mp, BTaskDev K, BState *__restrict__ states,
                                                          const float *__restrict__ act, float *__restrict__ obs, float *__restrict__ rew,
                                                          float *__restrict__ disc, int *__restrict__ st, int batch, int mode, int nphys,
-                                                         const int *__restrict__ order, int *__restrict__ cost) {
+                                                         const int *__restrict__ order, int *__restrict__ cost,
+                                                         const unsigned char *__restrict__ reset_mask) {
   // Workgroups are dispatched in index order; `order` lists the envs by decreasing cost of their previous control step, so the
   // expensive ones (more contacts, more Newton iterations) start first and the launch does not end on a few long waves
   // running alone at low occupancy (launch_order.hpp; walk_on_ball, B = 4 096: -3 % launch time).
   if ((int)blockIdx.x >= batch) return;
   const int env = order[blockIdx.x], lane = threadIdx.x;
+  if (mode == 3) {  // ffe_reset_envs: only the masked envs start a new episode; the others keep state and output rows
+    if (!reset_mask[env]) return;
+    mode = 1;
+  }
   __shared__ BTile T;
   const BallModel &M = *Mp;
   BState &S = states[env];
@@ -1351,10 +1358,12 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   // one copy of each stage: stage1 ; [stage2 ; stage1] x nsub.  A reset is stage1 ; stage2 without actuation and without
   // integrating (mj_forward, dm_control's after_reset); its sensors are the first sample of the buffers.
   if (do_reset) c.flags |= BF_NO_ACTUATION;
+  unsigned long long con_hist = 0ull;
 #pragma unroll 1
   for (int s = 0;; s++) {
     stage1(c);
     if (!do_reset && s == nsub) break;
+    if (s < 16) con_hist |= (unsigned long long)min(c.nact, 15) << (4 * s);
     float act_new;
     stage2(c, act_reg, ctrl_reg, act_new, !do_reset, iters, &qn2);
     if (do_reset) break;
@@ -1371,6 +1380,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
     S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc;
+    S.con_hist[0] = (unsigned)con_hist; S.con_hist[1] = (unsigned)(con_hist >> 32);
     cost[env] = iters;  // key of the next launch's order: Newton iterations over this step's substeps, what the launch time varies with
     if (do_reset) S.overflow = 0; else if (c.overflow) S.overflow = 1;
     S.have_ws = do_reset ? 0 : c.have_ws;
@@ -1467,7 +1477,7 @@ __global__ void ball_task_state_kernel(const BState *states, int *ints, double *
   if (i >= batch) return;
   const BState &S = states[i];
   int *o = ints + (size_t)i * 8;
-  o[0] = 0; o[1] = 0; o[2] = S.step_counter; o[3] = 0; o[4] = S.needs_reset; o[5] = S.ncon; o[6] = S.iters; o[7] = S.overflow;
+  o[0] = (int)S.con_hist[0]; o[1] = (int)S.con_hist[1]; o[2] = S.step_counter; o[3] = 0; o[4] = S.needs_reset; o[5] = S.ncon; o[6] = S.iters; o[7] = S.overflow;
   for (int k = 0; k < 8; k++) reals[(size_t)i * 8 + k] = 0.0;
 }
 
@@ -1489,12 +1499,12 @@ struct BallEnv {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+struct BallEnvDeleter { void operator()(BallEnv *e) const { ball_destroy(e); } };
+
+// the caller (fly_env.hip) has made `device` current
 BallEnv *ball_create(const void *blob, size_t blob_size, const BallTaskHost &task, int batch, int device) {
   if (!blob || batch <= 0) throw std::runtime_error("ffe_create_walk_on_ball: bad arguments");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device: the MI355X path has no CPU fallback");
-  HIPB_OK(hipSetDevice(device));
-  std::unique_ptr<BallEnv> e(new BallEnv());
+  std::unique_ptr<BallEnv, BallEnvDeleter> e(new BallEnv());  // frees the device allocations made so far if a later step throws
   Blob b(blob, blob_size);
   e->host = build_ball_model(b);
   e->device = device; e->batch = batch;
@@ -1517,7 +1527,6 @@ BallEnv *ball_create(const void *blob, size_t blob_size, const BallTaskHost &tas
 }
 void ball_destroy(BallEnv *e) {
   if (!e) return;
-  (void)hipSetDevice(e->device);
   if (e->model_dev) (void)hipFree(e->model_dev);
   if (e->states) (void)hipFree(e->states);
   if (e->order) (void)hipFree(e->order);
@@ -1532,11 +1541,13 @@ void ball_spec(const BallEnv *e, int *nq, int *nv, int *nu, int *action_dim, int
 void ball_action_bounds(const BallEnv *e, float *mn, float *mx) {
   for (int k = 0; k < NACT; k++) { mn[k] = e->host.action_min[k]; mx[k] = e->host.action_max[k]; }
 }
-void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys) {
-  if (mode != 1 && !act) throw std::runtime_error("walk_on_ball: null action buffer");
+void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys,
+                 const uint8_t *mask) {
+  if (mode != 1 && mode != 3 && !act) throw std::runtime_error("walk_on_ball: null action buffer");
   if (mode != 2 && (!obs || !rew || !disc || !st)) throw std::runtime_error("walk_on_ball: null output buffer");
+  if (mode == 3 && !mask) throw std::runtime_error("walk_on_ball: null reset mask");
   hipLaunchKernelGGL(ball_step_kernel, dim3(e->batch), dim3(64), 0, (hipStream_t)stream, e->model_dev, e->task, e->states, act, obs, rew, disc, st,
-                     e->batch, mode, nphys, e->order, e->cost);
+                     e->batch, mode, nphys, e->order, e->cost, mask);
   HIPB_OK(hipGetLastError());
   if (mode == 0 && e->batch > 1) {
     hipLaunchKernelGGL(ffe_order::order_by_cost, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->cost, e->order, e->batch);
@@ -1573,7 +1584,7 @@ extern "C" int ffb_debug_read_stamps(unsigned long long *out24, int reset) {
 float ball_time_steps(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   HIPB_OK(hipEventRecord(e->ev0, s));
-  for (int k = 0; k < iters; k++) ball_launch(e, act, obs, rew, disc, st, stream, 0, 0);
+  for (int k = 0; k < iters; k++) ball_launch(e, act, obs, rew, disc, st, stream, 0, 0, nullptr);
   HIPB_OK(hipEventRecord(e->ev1, s));
   HIPB_OK(hipEventSynchronize(e->ev1));
   float ms = 0.f;

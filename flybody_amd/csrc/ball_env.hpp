@@ -18,7 +18,9 @@ BallEnv *ball_create(const void *blob, size_t blob_size, const BallTaskHost &tas
 void ball_destroy(BallEnv *e);
 void ball_spec(const BallEnv *e, int *nq, int *nv, int *nu, int *action_dim, int *obs_dim, int *nsub, double *h, double *ctrl_dt);
 void ball_action_bounds(const BallEnv *e, float *mn, float *mx);
-void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys);
+// mode 0 step, 1 reset all, 2 bare physics (nphys steps), 3 reset the envs whose mask byte is set
+void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys,
+                 const uint8_t *mask);
 void ball_get_state(BallEnv *e, double *qpos, double *qvel, void *stream);
 void ball_set_state(BallEnv *e, const double *qpos, const double *qvel, void *stream);
 void ball_get_act(BallEnv *e, double *act, void *stream);

@@ -133,11 +133,20 @@ __device__ __forceinline__ float fsqrt(float x) {
 
 // One workgroup = one wavefront: LDS operations of a wave execute in issue order, so publishing a lane's LDS write to
 // the other lanes only needs the compiler not to reorder across this point.
+#ifdef FFE_LOCAL_FENCE
+#define DM_SYNC()                                                \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
+  } while (0)
+#else
 #define DM_SYNC()                                                \
   do {                                                           \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
     __builtin_amdgcn_wave_barrier();                             \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
+#endif
 
 }  // namespace dm

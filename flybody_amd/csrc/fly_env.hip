@@ -49,12 +49,13 @@ struct alignas(64) EnvState {
 };
 
 struct TaskDev {
-  int nfreq, ntraj, traj_len, future_steps, time_limit_steps, pad_first_obs, flags, obs_dim, canonical, clip;
+  int nfreq, ntraj, future_steps, time_limit_steps, episode_limit_steps, pad_first_obs, flags, obs_dim, canonical, clip;
   float act_lo[16], act_hi[16];
   double base_freq, rel_range, rate, dt_ctrl, terminal_com_dist, ghost_accel_z;
   const double FFE_GLOBAL *beat_freqs, *phase, *phase_frac, *ref_qpos, *ref_qvel;
   const float FFE_GLOBAL *traj;
   const int FFE_GLOBAL *tab_off;
+  const int FFE_GLOBAL *traj_off;  // [ntraj + 1] first reference row of each trajectory (ref: trajectory_loaders.py:98-100 ragged lengths)
   unsigned long long seed, env_id_base;
 };
 
@@ -325,6 +326,14 @@ __device__ __forceinline__ const DevModel FFE_CONST &model(const Ctx &c) {
 // write visible to another lane needs no hardware wait at all - only the compiler must not reorder across the point.
 #if defined(FFE_HW_SYNC)
 #define SYNC() __syncthreads()
+#elif defined(FFE_LOCAL_FENCE)
+// experiment: order LDS traffic only, so that global (model table) loads may be scheduled across the hand-off points
+#define SYNC()                                                      \
+  do {                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
+    __builtin_amdgcn_wave_barrier();                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
+  } while (0)
 #else
 #define SYNC()                                                   \
   do {                                                           \
@@ -1102,7 +1111,7 @@ __device__ __forceinline__ ObsLayout obs_layout(int nj, int nref) {
 
 // Observation assembly (ref: fruitfly.py:532-708 enabled set per tasks/base.py:167-168 + flight_imitation.py:84-85;
 // ref_displacement / ref_root_quat: tasks/base.py:237-261).  Returns |ref_displacement[0]| and ref_root_quat[0].
-__device__ void write_obs(Ctx &c, const TaskDev FFE_CONST &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_idx, int step_counter,
+__device__ void write_obs(Ctx &c, const TaskDev FFE_CONST &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_row0, int step_counter,
                           float &com_dist, Q4 &rq0) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
@@ -1122,7 +1131,7 @@ __device__ void write_obs(Ctx &c, const TaskDev FFE_CONST &K, float *obs, V3 s_a
   float cd = 0.f;
   Q4 r0 = {1.f, 0.f, 0.f, 0.f};
   if (lane < nref) {
-    const double *r = K.ref_qpos + ((size_t)traj_idx * K.traj_len + step_counter + lane) * 7;
+    const double *r = K.ref_qpos + ((size_t)traj_row0 + step_counter + lane) * 7;
     V3 dv = {(float)(r[0] - T.rootpos[0]), (float)(r[1] - T.rootpos[1]), (float)(r[2] - T.rootpos[2])};
     V3 e = mtv(ldm(T.xmat[0]), dv);
     obs[L.rdisp + 3 * lane] = e.x; obs[L.rdisp + 3 * lane + 1] = e.y; obs[L.rdisp + 3 * lane + 2] = e.z;
@@ -1148,7 +1157,8 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
 __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(const DevModel *__restrict__ Mp_, const TaskDev *__restrict__ Kp_, EnvState *__restrict__ states, const float *__restrict__ act,
                                                               float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                               float *__restrict__ discount_out, int *__restrict__ step_type_out, int batch, int mode, int nphys,
-                                                              const int *__restrict__ order, int *__restrict__ cost) {
+                                                              const int *__restrict__ order, int *__restrict__ cost,
+                                                              const unsigned char *__restrict__ reset_mask) {
   __shared__ Tile T;
   const DevModel FFE_CONST *Mp = (const DevModel FFE_CONST *)Mp_;
   const TaskDev FFE_CONST *Kp = (const TaskDev FFE_CONST *)Kp_;
@@ -1156,6 +1166,10 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   const TaskDev FFE_CONST &K = *Kp;
   if ((int)blockIdx.x >= batch) return;
   const int env = order[blockIdx.x];  // most expensive envs first (launch_order.hpp)
+  if (mode == 3) {  // ffe_reset_envs: only the masked envs start a new episode; the others keep state and output rows
+    if (!reset_mask[env]) return;
+    mode = 1;
+  }
   const int lane = threadIdx.x;
   EnvState &S = states[env];
   Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}, 0u};
@@ -1195,7 +1209,8 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
     wb_step = wave_argmin_absdiff(K.phase + off, len, phase, lane);
     const int nxt = wb_step + 1 < len ? wb_step + 1 : 0;  // the reference reads [step+1] unguarded
-    const double *rq = K.ref_qpos + (size_t)traj_idx * K.traj_len * 7, *rv = K.ref_qvel + (size_t)traj_idx * K.traj_len * 6;
+    const int row0 = K.traj_off[traj_idx];
+    const double *rq = K.ref_qpos + (size_t)row0 * 7, *rv = K.ref_qvel + (size_t)row0 * 6;
     if (lane < kMaxDof + 4) { T.qpos[lane] = lane < M.nq ? M.qpos0[lane] : 0.f; T.qvel[lane] = 0.f; }
     SYNC();
     if (lane == 0) {
@@ -1259,7 +1274,8 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     SYNC();
     ctrl_reg = lane < M.nu ? T.ctrl[lane] : 0.f;
     SYNC();
-    const double *rq = K.ref_qpos + ((size_t)traj_idx * K.traj_len + step_counter) * 7, *rv = K.ref_qvel + ((size_t)traj_idx * K.traj_len + step_counter) * 6;
+    const size_t row = (size_t)K.traj_off[traj_idx] + step_counter;
+    const double *rq = K.ref_qpos + row * 7, *rv = K.ref_qvel + row * 6;
     if (lane < 7) T.ghost[lane] = rq[lane];
     else if (lane < 13) T.ghost[lane] = rv[lane - 7];
     step_counter++;
@@ -1306,15 +1322,17 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   const float inv = (do_reset && K.pad_first_obs) ? 1.f : 1.f / (float)nsub;
   float cdist;
   Q4 rq0;
+  const int traj_row0 = K.traj_off[traj_idx], traj_rows = K.traj_off[traj_idx + 1] - traj_row0;
   if (c.flags & DBG_SKIP_OBS) { cdist = 0.f; rq0 = {1.f, 0.f, 0.f, 0.f}; }
-  else write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, traj_idx, step_counter, cdist, rq0);
+  else write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, traj_row0, step_counter, cdist, rq0);
   if (do_reset) {
     if (lane == 0) { reward_out[env] = 0.f; discount_out[env] = 1.f; step_type_out[env] = FFE_STEP_FIRST; S.needs_reset = 0; S.forced_traj = -1; }
   } else {
     // ---- check_termination (ref: flight_imitation.py:198-209, base.py:214-217); qacc is the last substep's
     float qn2 = wave_sum(lane < M.nv ? c.qacc * c.qacc : 0.f);
     float height = (float)T.rootpos[2];
-    int lim = K.traj_len < K.time_limit_steps ? K.traj_len : K.time_limit_steps;
+    // ref: flight_imitation.py:107-108, per episode: min(len(this trajectory), round(time_limit / control_timestep)) - (future_steps + 1)
+    int lim = traj_rows < K.time_limit_steps ? traj_rows : K.time_limit_steps;
     int traj_timesteps = lim - (K.future_steps + 1);
     bool reached_end = (step_counter == traj_timesteps);
     bool bad = !(qn2 == qn2) || !(sqrtf(qn2) <= 1e14f);
@@ -1334,7 +1352,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       float reward = r1 * r2;
       float discount = (term && !reached_end) ? 0.f : 1.f;
       if (bad || !(reward == reward)) { reward = 0.f; discount = 0.f; }
-      bool time_up = step_counter >= K.time_limit_steps;
+      bool time_up = step_counter >= K.episode_limit_steps;  // composer.Environment: physics.time() >= time_limit
       reward_out[env] = reward; discount_out[env] = discount;
       step_type_out[env] = (term || time_up) ? FFE_STEP_LAST : FFE_STEP_MID;
       S.needs_reset = (term || time_up) ? 1 : 0;
@@ -1440,9 +1458,24 @@ struct ffe_env {
   std::vector<void *> allocs;
   std::string err;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int *forced_traj_dev = nullptr;      // staging of ffe_force_next_episode (allocated on first use)
+  double *forced_phase_dev = nullptr;
 };
 
 static thread_local std::string g_err;
+
+// Every entry point runs on the handle's device and leaves the caller's current device untouched.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) { switched = (hipSetDevice(device) == hipSuccess); }
+  }
+  ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 #define HIP_OK(expr)                                                                              \
   do {                                                                                            \
@@ -1476,6 +1509,10 @@ int ffe_create_walk_on_ball(const void *model_blob, size_t blob_size, const ffe_
     if (!task) throw std::runtime_error("ffe_create_walk_on_ball: bad arguments");
     ffb::BallTaskHost t{task->time_limit_steps, task->pad_first_obs, task->physics_flags, task->canonical_actions, task->clip_actions,
                         task->control_timestep};
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device: the MI355X path has no CPU fallback");
+    if (device < 0 || device >= ndev) throw std::runtime_error("ffe_create_walk_on_ball: no such device");
+    DeviceGuard guard(device);
     h->ball = ffb::ball_create(model_blob, blob_size, t, batch, device);
     h->device = device; h->batch = batch;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
@@ -1484,11 +1521,13 @@ int ffe_create_walk_on_ball(const void *model_blob, size_t blob_size, const ffe_
 }
 int ffe_get_act(ffe_handle h, double *act_dev, void *stream) {
   if (!h || !act_dev || !h->ball) return -1;
+  DeviceGuard guard(h->device);
   FFE_BALL_DISPATCH(h, ffb::ball_get_act(h->ball, act_dev, stream));
   return -1;
 }
 int ffe_set_act(ffe_handle h, const double *act_dev, void *stream) {
   if (!h || !act_dev || !h->ball) return -1;
+  DeviceGuard guard(h->device);
   FFE_BALL_DISPATCH(h, ffb::ball_set_act(h->ball, act_dev, stream));
   return -1;
 }
@@ -1501,12 +1540,14 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
   if (!out) return -1;
   *out = nullptr;
   std::unique_ptr<ffe_env> h(new ffe_env());
+  std::unique_ptr<DeviceGuard> guard;
   try {
     if (!model_blob || !task || batch <= 0) throw std::runtime_error("ffe_create_flight: bad arguments");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw std::runtime_error("no HIP device: the MI355X path has no CPU fallback");
-    HIP_OK(hipSetDevice(device));
+    if (device < 0 || device >= ndev) throw std::runtime_error("ffe_create_flight: no such device");
+    guard.reset(new DeviceGuard(device));
     Blob blob(model_blob, blob_size);
     h->host = build_host_model(blob);
     h->device = device; h->batch = batch;
@@ -1516,7 +1557,13 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
     if (t.wb_nfreq <= 0 || !t.wb_beat_freqs || !t.wb_tab_off || !t.wb_traj || !t.wb_phase || t.ntraj <= 0 || t.traj_len <= 0 || !t.ref_qpos || !t.ref_qvel)
       throw std::runtime_error("ffe_create_flight: incomplete task tables");
     if (t.future_steps + 1 > kMaxFuture) throw std::runtime_error("future_steps too large");
-    if (t.traj_len < t.future_steps + 2) throw std::runtime_error("trajectories too short");
+    // per-trajectory row offsets (ref: trajectory_loaders.py:98-100 - trajectories of different lengths)
+    std::vector<int> toff((size_t)t.ntraj + 1);
+    for (int i = 0; i <= t.ntraj; i++) toff[i] = t.traj_off ? t.traj_off[i] : i * t.traj_len;
+    if (toff[0] != 0) throw std::runtime_error("traj_off[0] must be 0");
+    for (int i = 0; i < t.ntraj; i++)
+      if (toff[i + 1] - toff[i] < t.future_steps + 2) throw std::runtime_error("trajectories too short");
+    const size_t ref_rows = (size_t)toff[t.ntraj];
     if (h->dm.user_action < 0 || h->dm.nwing != 6) throw std::runtime_error("model is not the flight model");
     h->dm.nsub = (int)llround(t.wb_dt_ctrl / (double)blob.get("opt").f(0));
     const int rows = t.wb_tab_off[t.wb_nfreq];
@@ -1525,7 +1572,8 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
     for (int i = 0; i < rows; i++) frac[i] = std::fmod(t.wb_phase[i], 1.0);
     for (size_t i = 0; i < trajf.size(); i++) trajf[i] = (float)t.wb_traj[i];
     TaskDev &K = h->task;
-    K.nfreq = t.wb_nfreq; K.ntraj = t.ntraj; K.traj_len = t.traj_len; K.future_steps = t.future_steps; K.time_limit_steps = t.time_limit_steps;
+    K.nfreq = t.wb_nfreq; K.ntraj = t.ntraj; K.future_steps = t.future_steps; K.time_limit_steps = t.time_limit_steps;
+    K.episode_limit_steps = t.episode_limit_steps > 0 ? t.episode_limit_steps : t.time_limit_steps;
     K.pad_first_obs = t.pad_first_obs; K.flags = t.physics_flags; K.canonical = t.canonical_actions; K.clip = t.clip_actions;
     for (int k = 0; k < 16; k++) { K.act_lo[k] = k < h->dm.naction ? h->host.action_min[k] : 0.f; K.act_hi[k] = k < h->dm.naction ? h->host.action_max[k] : 0.f; }
     K.base_freq = t.wb_base_freq; K.rel_range = t.wb_rel_range; K.rate = t.wb_rate; K.dt_ctrl = t.wb_dt_ctrl;
@@ -1535,8 +1583,9 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
     set_off(K.phase, (size_t)upload(h.get(), t.wb_phase, (size_t)rows));
     set_off(K.phase_frac, (size_t)upload(h.get(), frac.data(), frac.size()));
     set_off(K.traj, (size_t)upload(h.get(), trajf.data(), trajf.size()));
-    set_off(K.ref_qpos, (size_t)upload(h.get(), t.ref_qpos, (size_t)t.ntraj * t.traj_len * 7));
-    set_off(K.ref_qvel, (size_t)upload(h.get(), t.ref_qvel, (size_t)t.ntraj * t.traj_len * 6));
+    set_off(K.ref_qpos, (size_t)upload(h.get(), t.ref_qpos, ref_rows * 7));
+    set_off(K.ref_qvel, (size_t)upload(h.get(), t.ref_qvel, ref_rows * 6));
+    set_off(K.traj_off, (size_t)upload(h.get(), toff.data(), toff.size()));
     K.seed = seed; K.env_id_base = env_id_base;
     K.obs_dim = 12 + 2 * h->dm.nobsj + 7 * (t.future_steps + 1);
     h->host.nobs = K.obs_dim;
@@ -1556,6 +1605,8 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
   } catch (const std::exception &e) {
     g_err = e.what();
     for (void *p : h->allocs) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     return -1;
   }
   *out = h.release();
@@ -1564,8 +1615,8 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
 
 int ffe_destroy(ffe_handle h) {
   if (!h) return -1;
+  DeviceGuard guard(h->device);
   if (h->ball) { ffb::ball_destroy(h->ball); delete h; return 0; }
-  (void)hipSetDevice(h->device);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1603,12 +1654,14 @@ int ffe_action_bounds(ffe_handle h, float *mn, float *mx) {
   return 0;
 }
 
-static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys = 0) {
+static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys = 0,
+                       const uint8_t *mask = nullptr) {
   if (!h) return -1;
-  FFE_BALL_DISPATCH(h, ffb::ball_launch(h->ball, act, obs, rew, disc, st, stream, mode, nphys));
+  DeviceGuard guard(h->device);
+  FFE_BALL_DISPATCH(h, ffb::ball_launch(h->ball, act, obs, rew, disc, st, stream, mode, nphys, mask));
   if (mode != 2 && (!obs || !rew || !disc || !st || (mode == 0 && !act))) { h->err = "null device buffer"; return -1; }
   hipLaunchKernelGGL(flight_step_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->dm_dev, h->task_dev, h->states, act, obs, rew,
-                     disc, st, h->batch, mode, nphys, h->order, h->cost);
+                     disc, st, h->batch, mode, nphys, h->order, h->cost, mask);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
   // measured: +2 % env-steps/s at B = 8 192 (two rounds of the 4 096 resident waves); beyond that the tail the order shortens
@@ -1622,6 +1675,11 @@ static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, f
 }
 
 int ffe_reset(ffe_handle h, float *obs, float *rew, float *disc, int32_t *st, void *stream) { return launch_step(h, nullptr, obs, rew, disc, st, stream, 1); }
+int ffe_reset_envs(ffe_handle h, const uint8_t *mask, float *obs, float *rew, float *disc, int32_t *st, void *stream) {
+  if (!h) return -1;
+  if (!mask) { h->err = "null reset mask"; return -1; }
+  return launch_step(h, nullptr, obs, rew, disc, st, stream, 3, 0, mask);
+}
 int ffe_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream) {
   return launch_step(h, act, obs, rew, disc, st, stream, 0);
 }
@@ -1631,36 +1689,48 @@ int ffe_physics_step(ffe_handle h, const float *ctrl, int nsteps, void *stream) 
   return launch_step(h, ctrl, nullptr, nullptr, nullptr, nullptr, stream, 2, nsteps);
 }
 
-int ffe_force_next_episode(ffe_handle h, const int32_t *traj, const double *phase) {
+int ffe_force_next_episode(ffe_handle h, const int32_t *traj, const double *phase, void *stream) {
   if (!h || !traj || !phase) return -1;
   if (h->ball) { h->err = "walk_on_ball episodes have no per-episode randomness"; return -1; }
+  DeviceGuard guard(h->device);
   try {
-    int *dt = nullptr; double *dp = nullptr;
-    HIP_OK(hipMalloc(reinterpret_cast<void **>(&dt), sizeof(int) * h->batch));
-    HIP_OK(hipMalloc(reinterpret_cast<void **>(&dp), sizeof(double) * h->batch));
-    HIP_OK(hipMemcpy(dt, traj, sizeof(int) * h->batch, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(dp, phase, sizeof(double) * h->batch, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(force_next_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, 0, h->states, dt, dp, h->batch);
-    HIP_OK(hipDeviceSynchronize());
-    (void)hipFree(dt); (void)hipFree(dp);
+    for (int i = 0; i < h->batch; i++)
+      if (traj[i] >= h->task.ntraj) throw std::runtime_error("ffe_force_next_episode: trajectory index out of range");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->forced_traj_dev) {
+      HIP_OK(hipMalloc(reinterpret_cast<void **>(&h->forced_traj_dev), sizeof(int) * h->batch));
+      h->allocs.push_back(h->forced_traj_dev);
+      HIP_OK(hipMalloc(reinterpret_cast<void **>(&h->forced_phase_dev), sizeof(double) * h->batch));
+      h->allocs.push_back(h->forced_phase_dev);
+    }
+    // pageable host memory: the copies are staged before the calls return, ordered on `s` with the kernel below; the stream
+    // is synchronised once so that a second call cannot overwrite the staging buffers under a pending kernel
+    HIP_OK(hipMemcpyAsync(h->forced_traj_dev, traj, sizeof(int) * h->batch, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(h->forced_phase_dev, phase, sizeof(double) * h->batch, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(force_next_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, s, h->states, h->forced_traj_dev, h->forced_phase_dev, h->batch);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(s));
   } catch (const std::exception &e) { h->err = e.what(); return -1; }
   return 0;
 }
 
 int ffe_get_state(ffe_handle h, double *qpos, double *qvel, void *stream) {
   if (!h || !qpos || !qvel) return -1;
+  DeviceGuard guard(h->device);
   FFE_BALL_DISPATCH(h, ffb::ball_get_state(h->ball, qpos, qvel, stream));
   hipLaunchKernelGGL(get_state_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->states, qpos, qvel, h->batch, h->dm.nq, h->dm.nv);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int ffe_set_state(ffe_handle h, const double *qpos, const double *qvel, void *stream) {
   if (!h || !qpos || !qvel) return -1;
+  DeviceGuard guard(h->device);
   FFE_BALL_DISPATCH(h, ffb::ball_set_state(h->ball, qpos, qvel, stream));
   hipLaunchKernelGGL(set_state_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->states, qpos, qvel, h->batch, h->dm.nq, h->dm.nv);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int ffe_get_task_state(ffe_handle h, int32_t *ints, double *reals, void *stream) {
   if (!h || !ints || !reals) return -1;
+  DeviceGuard guard(h->device);
   FFE_BALL_DISPATCH(h, ffb::ball_get_task_state(h->ball, ints, reals, stream));
   hipLaunchKernelGGL(get_task_state_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), h->states, ints, reals, h->batch);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1668,6 +1738,7 @@ int ffe_get_task_state(ffe_handle h, int32_t *ints, double *reals, void *stream)
 
 int ffe_time_steps(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream, float *ms) {
   if (!h || !ms || iters <= 0) return -1;
+  DeviceGuard guard(h->device);
   FFE_BALL_DISPATCH(h, *ms = ffb::ball_time_steps(h->ball, act, obs, rew, disc, st, iters, stream));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipEventRecord(h->ev0, s) != hipSuccess) return -2;

@@ -21,8 +21,10 @@ def flight_imitation(wpg_pattern_path: str | None = None, ref_path: str | None =
     Args:
         wpg_pattern_path: `.npy` with one wing-beat cycle, shape (timesteps, 3) [yaw, roll, pitch], as the
             reference's WingBeatPatternGenerator expects.  None = the build's synthetic cycle.
-        ref_path: `.npz` with `com_qpos (N,T,7)`, `com_qvel (N,T,6)`, `timestep_seconds` (the reference's HDF5 layout,
-            `tasks/trajectory_loaders.py:90-96`, converted; h5py is unavailable).  None = synthetic trajectories.
+        ref_path: `.npz` written by `tools/convert_hdf5_to_npz.py` from the reference's HDF5 layout
+            (`tasks/trajectory_loaders.py:90-96`; h5py is unavailable here): `com_qpos (rows,7)`, `com_qvel (rows,6)`,
+            `traj_off (N+1,)`, `timestep_seconds` - every trajectory keeps its own length, as in the reference.
+            None = synthetic trajectories.
         random_state: int seed or `np.random.RandomState`; seeds the per-env counter-based generators that draw the
             trajectory index and the initial wing-beat phase of every episode.
         terminal_com_dist: episode terminates when the model-to-ghost CoM distance exceeds this (cm).
@@ -33,18 +35,18 @@ def flight_imitation(wpg_pattern_path: str | None = None, ref_path: str | None =
     else:
         tables = wbpg.load_tables(wpg_pattern_path)
     if ref_path is None:
-        com_qpos, com_qvel = synthetic.flight_trajectories()
+        refs = trajectories.as_refset(*trajectories.preprocess(*synthetic.flight_trajectories()))
     else:
         com_qpos, com_qvel, dt = trajectories.load_npz(ref_path)
         if abs(dt - tables.dt_ctrl) > 1e-12:
             raise ValueError(f"trajectory timestep {dt} != control timestep {tables.dt_ctrl}")
-    ref_qpos, ref_qvel = trajectories.preprocess(com_qpos, com_qvel)
+        refs = trajectories.preprocess_ragged(com_qpos, com_qvel)
     if isinstance(random_state, np.random.RandomState):
         seed = int(random_state.randint(0, 2**31 - 1))
     else:
         seed = 0 if random_state is None else int(random_state)
     # fly_envs.py:54-65: time_limit 0.6 s, joint_filter 0 (compiled into the model), future_steps 5, initialize_qvel
-    return BatchedFlyEnv(tables, ref_qpos, ref_qvel, batch_size=batch_size, device=device, seed=seed, env_id_base=env_id_base,
+    return BatchedFlyEnv(tables, refs, batch_size=batch_size, device=device, seed=seed, env_id_base=env_id_base,
                          future_steps=5, time_limit=0.6, terminal_com_dist=terminal_com_dist, **env_kwargs)
 
 

@@ -10,7 +10,8 @@
  *   - every function returns 0 on success, <0 on error (ffe_last_error() has the text); nothing throws;
  *   - all "dev" pointers are device (HBM) buffers owned by the caller; the library owns env state;
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and never synchronise;
- *   - one handle per (device, stream); handles are not thread-safe;
+ *   - one handle per (device, stream); handles are not thread-safe; every entry point runs on the handle's device
+ *     whatever the caller's current device is, and leaves the caller's current device as it found it;
  *   - layouts are row-major with the env index leading: act[B][A], obs[B][O].
  */
 #ifndef FLYBODY_ENV_H_
@@ -43,12 +44,20 @@ typedef struct {
   const double *wb_traj;       /* [rows][6] wing angles */
   const double *wb_phase;      /* [rows] */
   double wb_base_freq, wb_rel_range, wb_rate, wb_dt_ctrl;
-  /* reference trajectories after the per-episode preprocessing of flight_imitation.py:97-104 */
+  /* reference trajectories after the per-episode preprocessing of flight_imitation.py:97-104.  The reference serves
+   * trajectories of different lengths (trajectory_loaders.py:98-100,124-129): rows of all trajectories are concatenated
+   * and `traj_off[ntraj + 1]` holds the first row of each; traj_off == NULL means every trajectory has `traj_len` rows. */
   int32_t ntraj, traj_len;
-  const double *ref_qpos; /* [ntraj][traj_len][7] ghost root pose */
-  const double *ref_qvel; /* [ntraj][traj_len][6] */
+  const double *ref_qpos; /* [rows][7] ghost root pose */
+  const double *ref_qvel; /* [rows][6] */
+  const int32_t *traj_off; /* [ntraj + 1] or NULL */
   int32_t future_steps;     /* fly_envs.py:65 (5) */
-  int32_t time_limit_steps; /* round(time_limit / control_timestep), fly_envs.py:54 (3000) */
+  int32_t time_limit_steps; /* round(time_limit / control_timestep), fly_envs.py:54 (3000): caps `_traj_timesteps`
+                               (flight_imitation.py:107-108: min(len(trajectory), this) - (future_steps + 1)) */
+  int32_t episode_limit_steps; /* control steps after which composer.Environment's `physics.time() >= time_limit` fires;
+                                  MuJoCo's time is a float64 running sum of the physics timestep, so this is 3001, not
+                                  3000, for 0.6 s at 5e-5 s (flybody_amd/batched_env.py:time_limit_control_steps);
+                                  <= 0 means time_limit_steps */
   double terminal_com_dist; /* fly_envs.py:33 (2.0) */
   double ghost_accel_z;     /* gravity felt by the armature-1 ghost, cm/s^2 */
   int32_t pad_first_obs;    /* 0 = dm_control zero-padded sensor buffers at reset */
@@ -64,7 +73,9 @@ typedef struct {
  * (tasks/walk_on_ball.py:21,41-42) are compiled into the model blob (flybody_amd/assets/fly_ball.ffmb). */
 typedef struct {
   double control_timestep;  /* tasks/constants.py:17 (2e-3 s; the model carries the 2e-4 s physics step) */
-  int32_t time_limit_steps; /* round(time_limit / control_timestep), fly_envs.py:144 (1000) */
+  int32_t time_limit_steps; /* control steps after which `physics.time() >= time_limit` fires (fly_envs.py:144, 2.0 s):
+                               1001 - ten thousand float64 additions of 2e-4 give 1.9999999999998 - see
+                               flybody_amd/batched_env.py:time_limit_control_steps */
   int32_t pad_first_obs;    /* 0 = dm_control zero-padded sensor buffers at reset */
   int32_t physics_flags;    /* FFE_NO_* */
   int32_t canonical_actions, clip_actions; /* acme.wrappers.CanonicalSpecWrapper folded in, as in ffe_flight_task */
@@ -105,6 +116,11 @@ int ffe_action_bounds(ffe_handle h, float *minimum, float *maximum);
  * FIRST.  Outputs as in ffe_step. */
 int ffe_reset(ffe_handle h, float *obs_dev, float *reward_dev, float *discount_dev, int32_t *step_type_dev,
               void *stream);
+/* Environment.reset() of a subset (one composer.Environment per actor in the reference, each reset on its own:
+ * ray_distributed_dmpo.py:401-404; evaluators restart episodes at will): envs with mask_dev[i] != 0 start a new
+ * episode and report FIRST; the state and the output rows of the other envs are left untouched. */
+int ffe_reset_envs(ffe_handle h, const uint8_t *mask_dev, float *obs_dev, float *reward_dev, float *discount_dev,
+                   int32_t *step_type_dev, void *stream);
 /* Environment.step(action) (ray_distributed_dmpo.py:404 via acme.EnvironmentLoop.run_episode): one control step of
  * every env = before_step, nsub physics substeps, reward, discount, termination, observation
  * (tasks/flight_imitation.py:149-220, tasks/base.py:190-217).  An env that returned LAST performs its reset on
@@ -120,15 +136,19 @@ int ffe_physics_step(ffe_handle h, const float *ctrl_dev, int nsteps, void *stre
 
 /* FlightImitationWBPG.set_next_trajectory_index (flight_imitation.py:87-91), plus the initial wing-beat phase
  * the reference draws from its RandomState (flight_imitation.py:137).  Host arrays [B]; traj_idx<0 keeps the
- * counter-based draw.  Applies to each env's next reset only. */
-int ffe_force_next_episode(ffe_handle h, const int32_t *traj_idx_host, const double *phase_host);
+ * counter-based draw.  Applies to each env's next reset only.  The host arrays are staged on `stream` and may be reused
+ * as soon as the call returns. */
+int ffe_force_next_episode(ffe_handle h, const int32_t *traj_idx_host, const double *phase_host, void *stream);
 
 /* physics.get_state()/set_state() analogue for parity tests: qpos[B][nq] (root position first), qvel[B][nv],
  * float64 device buffers.  set_state leaves task counters untouched. */
 int ffe_get_state(ffe_handle h, double *qpos_dev, double *qvel_dev, void *stream);
 int ffe_set_state(ffe_handle h, const double *qpos_dev, const double *qvel_dev, void *stream);
 /* task-side state per env: {wbpg_step, wbpg_freq_idx, step_counter, traj_idx, needs_reset, n_active_limits,
- * solver_iters, reserved} int32[B][8] and {wbpg_ctrl_freq, ghost_pos[3], ghost_quat[4]} float64[B][8] */
+ * solver_iters, reserved} int32[B][8] and {wbpg_ctrl_freq, ghost_pos[3], ghost_quat[4]} float64[B][8].
+ * walk_on_ball handles: {contact history lo, hi, step_counter, 0, needs_reset, contacts, solver_iters, overflow} - the
+ * contact history holds, 4 bits per substep for the first 16 substeps of the last control step, the number of contacts
+ * inside their includemargin (the ones that received constraint rows); reals are zero */
 int ffe_get_task_state(ffe_handle h, int32_t *ints_dev, double *reals_dev, void *stream);
 
 /* name and duration helper for bench.py's roofline: launches `iters` steps bracketed by HIP events on `stream`

@@ -80,7 +80,7 @@ def lib():
         L.fo_u01.argtypes = [C.c_uint64]
         L.fo_env_new.restype = vp
         L.fo_env_new.argtypes = [vp, C.c_int, dp, ip, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double,
-                                 C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64]
+                                 C.c_int, ip, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64]
         L.fo_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_env_force_next.argtypes = [vp, C.c_int, C.c_double]
         L.fo_env_set_pad_first_obs.argtypes = [vp, C.c_int]
@@ -100,7 +100,7 @@ def lib():
         L.fo_debug_ray_capsule.restype = C.c_double
         L.fo_debug_ray_capsule.argtypes = [dp, dp, C.c_double, C.c_double]
         L.fo_ball_env_new.restype = vp
-        L.fo_ball_env_new.argtypes = [vp, C.c_double, C.c_int]
+        L.fo_ball_env_new.argtypes = [vp, C.c_double, C.c_double]
         L.fo_ball_env_data.restype = vp
         L.fo_ball_env_data.argtypes = [vp]
         L.fo_ball_env_set_pad_first_obs.argtypes = [vp, C.c_int]
@@ -108,6 +108,7 @@ def lib():
         L.fo_ball_obs_dim.restype = C.c_int
         L.fo_ball_obs_dim.argtypes = [vp]
         L.fo_ball_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
+        L.fo_ball_env_hist.argtypes = [vp, ip, dp, C.c_int]
         L.fo_env_counters.restype = C.c_int
         L.fo_env_counters.argtypes = [vp, ip, ip]
     return _lib
@@ -253,27 +254,38 @@ class OracleFlightEnv:
     """Single-instance float64 flight-imitation env (dm_env semantics, one call = one control step).
 
     `wbpg` is a `flybody_amd.tasks.wbpg.WingBeatTables`-like object (attributes beat_freqs, tab_off, traj,
-    phase, base_freq, rel_range, rate, dt_ctrl); `refs` holds preprocessed `ref_qpos (N,T,7)` root poses
-    and `ref_qvel (N,T,6)`."""
+    phase, base_freq, rel_range, rate, dt_ctrl).  The preprocessed references come either stacked, `ref_qpos (N,T,7)`
+    root poses and `ref_qvel (N,T,6)`, or as one object with `qpos (rows,7)`, `qvel (rows,6)`, `off (N+1,)` (trajectories of
+    individual lengths, `trajectory_loaders.py:98-100`).  `time_limit` is in seconds (`fly_envs.py:54`)."""
 
     OBS = 104
 
-    def __init__(self, model: OracleModel, wbpg, ref_qpos, ref_qvel, *, future_steps=5, time_limit_steps=3000,
+    def __init__(self, model: OracleModel, wbpg, ref_qpos, ref_qvel=None, *, future_steps=5, time_limit=0.6,
                  terminal_com_dist=2.0, ghost_accel_z=0.0, seed=0, env_id=0):
+        if ref_qvel is None:
+            rq, rv, roff = ref_qpos.qpos, ref_qpos.qvel, ref_qpos.off
+        else:
+            rq, rv = np.asarray(ref_qpos, dtype=np.float64), np.asarray(ref_qvel, dtype=np.float64)
+            n_, t_ = rq.shape[:2]
+            rq, rv, roff = rq.reshape(n_ * t_, 7), rv.reshape(n_ * t_, 6), np.arange(n_ + 1) * t_
         self.model, self.L = model, model.L
         self._keep = dict(
             bf=np.ascontiguousarray(wbpg.beat_freqs, dtype=np.float64),
             off=np.ascontiguousarray(wbpg.tab_off, dtype=np.int32),
             traj=np.ascontiguousarray(wbpg.traj, dtype=np.float64),
             phase=np.ascontiguousarray(wbpg.phase, dtype=np.float64),
-            rq=np.ascontiguousarray(ref_qpos, dtype=np.float64),
-            rv=np.ascontiguousarray(ref_qvel, dtype=np.float64),
+            rq=np.ascontiguousarray(rq, dtype=np.float64),
+            rv=np.ascontiguousarray(rv, dtype=np.float64),
+            roff=np.ascontiguousarray(roff, dtype=np.int32),
         )
         k = self._keep
-        n, t = k["rq"].shape[:2]
+        n = len(k["roff"]) - 1
+        # flight_imitation.py:107: round(time_limit / control_timestep) caps the trajectory-end rule; the episode time limit
+        # itself is tested on the accumulated physics time inside the oracle
+        time_limit_steps = int(round(time_limit / wbpg.dt_ctrl))
         self.ptr = self.L.fo_env_new(model.ptr, len(k["bf"]), _dp(k["bf"]), _ip(k["off"]), _dp(k["traj"]), _dp(k["phase"]),
                                      float(wbpg.base_freq), float(wbpg.rel_range), float(wbpg.rate), float(wbpg.dt_ctrl),
-                                     n, t, _dp(k["rq"]), _dp(k["rv"]), future_steps, time_limit_steps,
+                                     n, _ip(k["roff"]), _dp(k["rq"]), _dp(k["rv"]), future_steps, time_limit_steps, float(time_limit),
                                      float(terminal_com_dist), float(ghost_accel_z), seed, env_id)
         self.data = OracleData(model, self.L.fo_env_data(self.ptr))
         self.naction = model.naction
@@ -329,9 +341,9 @@ class OracleBallEnv:
     LAYOUT = (("accelerometer", 3), ("actuator_activation", 59), ("appendages_pos", 21), ("ball_qvel", 3), ("force", 18),
               ("gyro", 3), ("joints_pos", 85), ("joints_vel", 85), ("touch", 6), ("velocimeter", 3), ("world_zaxis", 3))
 
-    def __init__(self, model: OracleModel, control_timestep=2e-3, time_limit_steps=1000):
+    def __init__(self, model: OracleModel, control_timestep=2e-3, time_limit=2.0):
         self.model, self.L = model, model.L
-        self.ptr = self.L.fo_ball_env_new(model.ptr, float(control_timestep), int(time_limit_steps))
+        self.ptr = self.L.fo_ball_env_new(model.ptr, float(control_timestep), float(time_limit))
         self.data = OracleData(model, self.L.fo_ball_env_data(self.ptr))
         self.naction = model.naction
         self.OBS = self.L.fo_ball_obs_dim(model.ptr)
@@ -349,6 +361,13 @@ class OracleBallEnv:
         r, dsc, st = C.c_double(), C.c_double(), C.c_int()
         self.L.fo_ball_env_step(self.ptr, _dp(a), _dp(obs), C.byref(r), C.byref(dsc), C.byref(st))
         return st.value, r.value, dsc.value, obs
+
+    def contact_history(self, n=10):
+        """Per substep of the last control step: (contacts inside their includemargin, smallest |dist - includemargin| over
+        all candidate pairs) - what the GPU parity tests use to tell a contact flip from a numerical error."""
+        counts, gaps = np.zeros(n, dtype=np.int32), np.zeros(n)
+        self.L.fo_ball_env_hist(self.ptr, _ip(counts), _dp(gaps), n)
+        return counts, gaps
 
     def split(self, obs):
         out, o = {}, 0

@@ -10,6 +10,10 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 BALL_BLOB = os.path.join(ROOT, "flybody_amd", "assets", "fly_ball.ffmb")
+# teacher-forced single control step, env-steps without a contact flip: max error per observation group, relative to the
+# group's magnitude (set to <= 3x the measured maxima, see test_env_protocol_and_observation_parity)
+TOL = {"reward": 3e-4, "accelerometer": 1e-6, "actuator_activation": 1e-6, "appendages_pos": 1e-5, "ball_qvel": 3e-3, "force": 3e-3,
+       "gyro": 1e-6, "joints_pos": 1e-5, "joints_vel": 3e-3, "touch": 3e-3, "velocimeter": 1e-6, "world_zaxis": 1e-6}
 
 
 @pytest.fixture(scope="module")
@@ -98,7 +102,7 @@ def test_one_substep_teacher_forced(torch_mod, flags, name):
         print("contacts oracle", [r[3][0][0] for r in ref], "gpu", ints[:, 5].tolist(), "iters oracle", [r[3][0][2] for r in ref], "gpu", ints[:, 6].tolist())
     assert ea < 1e-6
     assert eq < 2e-6, name   # qpos moves by h * qvel: 2e-4 * O(10)
-    assert ev < 2e-3, name   # one substep of contact forces at float32
+    assert ev < 1.5e-4, name   # one substep of contact forces at float32 (measured 5e-5 with noslip, 3e-6 without)
 
 
 def test_ten_substeps_open_loop(torch_mod):
@@ -121,13 +125,26 @@ def _obs_groups():
     return out
 
 
+def _gpu_contact_history(env, n=10):
+    """Per substep of the last control step: contacts inside their includemargin (ffe_get_task_state columns 0-1)."""
+    ints, _ = env.get_task_state()
+    ints = ints.cpu().numpy().astype(np.int64)
+    word = (ints[:, 0] & 0xffffffff) | ((ints[:, 1] & 0xffffffff) << 32)
+    return np.stack([(word >> (4 * s)) & 15 for s in range(n)], axis=1)
+
+
 def test_env_protocol_and_observation_parity(torch_mod):
     """reset + 30 control steps with identical random raw actions: FIRST / MID protocol, reward, every observation group.
 
-    Contact make/break is a discontinuity of the time stepping (a claw whose distance crosses 0 one substep earlier gets one
-    more substep of contact force), so an open-loop comparison of a contact-rich rollout amplifies float32 rounding by
-    orders of magnitude within a few control steps.  The oracle is therefore teacher-forced: before every control step it
-    is put on the HIP env's state, and one full control step (10 substeps + sensors + reward) is compared."""
+    Contact make/break is a discontinuity of the time stepping (a claw whose distance crosses its includemargin one substep
+    earlier gets one more substep of contact force), so an open-loop comparison of a contact-rich rollout amplifies float32
+    rounding by orders of magnitude within a few control steps.  The oracle is therefore teacher-forced: before every
+    control step it is put on the HIP env's state, and one full control step (10 substeps + sensors + reward) is compared.
+
+    Every compared env-step is classified by its per-substep contact history (contacts inside their includemargin, from
+    both sides): where the histories agree the step is held to float32 accuracy, with no allowance; where they differ (a
+    *contact flip*) the oracle must show that some candidate pair sat within 2e-6 cm of its switching distance during that
+    control step - otherwise the difference is a bug, not rounding - and the flips are counted and bounded."""
     from flybody_amd import fly_envs
     from oracle import oracle as O
 
@@ -147,10 +164,10 @@ def test_env_protocol_and_observation_parity(torch_mod):
         err = max(np.abs(obs[i, lo:hi] - ref0[i][3][lo:hi]).max() / max(1.0, np.abs(ref0[i][3][lo:hi]).max()) for i in range(B))
         worst[name] = err
     print("reset obs errors", {k: f"{v:.2e}" for k, v in worst.items()})
-    assert max(worst.values()) < 1e-4
+    assert max(worst.values()) < 1e-5
     rs = np.random.RandomState(0)
-    werr = {k: [] for k in groups}
-    rerr = []
+    werr = {k: [] for k in groups}   # non-flip env-steps
+    rerr, flip_rerr, flip_gaps = [], [], []
     for t in range(30):
         q, v = env.get_state()
         ac = env.get_act()
@@ -160,26 +177,32 @@ def test_env_protocol_and_observation_parity(torch_mod):
         torch.cuda.synchronize()
         obs = env.flat_observation.cpu().numpy()
         rew = ts.reward.cpu().numpy()
+        ghist = _gpu_contact_history(env)
         for i, e in enumerate(oenvs):
             d = e.data
             d.qpos[:], d.qvel[:], d.act[:] = q[i], v[i], ac[i]
             d.step1()
             st, r, dsc, o = e.step(a[i].astype(np.float32).astype(np.float64))
             assert st == int(ts.step_type[i]) and dsc == float(ts.discount[i])
+            ohist, ogap = e.contact_history()
+            if (ohist != ghist[i]).any():
+                flip_rerr.append(abs(r - rew[i])); flip_gaps.append(float(ogap.min()))
+                continue
             rerr.append(abs(r - rew[i]))
             for name, (lo, hi) in groups.items():
                 werr[name].append(np.abs(obs[i, lo:hi] - o[lo:hi]).max() / max(1.0, np.abs(o[lo:hi]).max()))
-    # A control step is 10 substeps: a claw whose distance crosses zero within float32 rounding of a substep boundary is
-    # active one substep earlier or later on one side, which moves that env's reward by ~1e-3.  Those are rare, so the
-    # typical (90th percentile) error is held to float32 accuracy and the worst case to the size of one such event.
-    p90 = {k: float(np.percentile(v, 90)) for k, v in werr.items()}
     mx = {k: float(np.max(v)) for k, v in werr.items()}
-    print("30 teacher-forced control steps x 8 envs: 90th percentile obs errors", {k: f"{v:.2e}" for k, v in p90.items()})
-    print("   max obs errors", {k: f"{v:.2e}" for k, v in mx.items()}, "reward p90 %.2e max %.2e" % (np.percentile(rerr, 90), np.max(rerr)))
-    assert np.percentile(rerr, 90) < 1e-4 and np.max(rerr) < 2e-2
-    assert p90["joints_pos"] < 1e-5 and p90["actuator_activation"] < 1e-6 and p90["appendages_pos"] < 1e-5
-    assert p90["joints_vel"] < 2e-3 and p90["ball_qvel"] < 1e-3 and p90["force"] < 1e-2 and p90["touch"] < 1e-2
-    assert mx["joints_pos"] < 1e-3 and mx["actuator_activation"] < 1e-6
+    n_all = len(rerr) + len(flip_rerr)
+    print(f"30 teacher-forced control steps x 8 envs: {len(flip_rerr)} contact flips in {n_all} env-steps "
+          f"(reward err on flips max {max(flip_rerr, default=0.0):.2e}, closest switching distance {max(flip_gaps, default=0.0):.2e} cm)")
+    print("   non-flip steps: max obs errors", {k: f"{v:.2e}" for k, v in mx.items()}, "reward max %.2e" % np.max(rerr))
+    assert len(flip_rerr) <= 0.05 * n_all
+    assert all(g < 2e-6 for g in flip_gaps), flip_gaps      # a flip needs a pair at its switching distance (float32 rounding of ~0.5 cm positions)
+    assert max(flip_rerr, default=0.0) < 2e-2               # one substep of one claw's contact force
+    # no contact flip: float32 accuracy, max over all such env-steps (bounds = 3x the values measured on MI355X, profiles/r02_gpu_tests.log)
+    assert np.max(rerr) < TOL["reward"]
+    for name in groups:
+        assert mx[name] < TOL[name], (name, mx[name])
     env.close()
 
 
@@ -215,7 +238,8 @@ def test_time_limit_autoreset_and_determinism(torch_mod):
     from flybody_amd.batched_env import BatchedBallEnv
 
     torch = torch_mod
-    env = BatchedBallEnv(batch_size=4, time_limit=0.01)  # 5 control steps
+    env = BatchedBallEnv(batch_size=4, time_limit=0.01)  # 5 control steps: 50 float64 additions of 2e-4 reach 0.01
+    assert env.spec.nsub == 10
     env.reset()
     a = torch.zeros(4, 59, dtype=torch.float32, device="cuda")
     types = []
@@ -253,7 +277,9 @@ def test_config3_batch_rollout_properties(torch_mod):
 
 def test_config1_single_env_1000_random_steps(torch_mod):
     """BASELINE configs[0]: walk_on_ball, 1 env, 1000 random-action control steps (raw U(-0.2, 0.2), `task_utils.py:13-24`).
-    The episode runs to the 2.0 s time limit: MID for 999 steps, LAST (discount 1) on step 1000, FIRST on the next call."""
+    The episode runs to the 2.0 s time limit, which composer.Environment tests on MuJoCo's accumulated float64 time: 10 000
+    additions of 2e-4 give 1.9999999999998, so the reference's episode has 1001 control steps - MID for 1000 steps, LAST
+    (discount 1) on step 1001, FIRST on the next call."""
     from flybody_amd import fly_envs
 
     torch = torch_mod
@@ -262,10 +288,10 @@ def test_config1_single_env_1000_random_steps(torch_mod):
     assert int(ts.step_type[0]) == 0
     g = torch.Generator(device="cuda").manual_seed(0)
     total = 0.0
-    for k in range(1000):
+    for k in range(1001):
         ts = env.step((torch.rand(1, 59, device="cuda", generator=g) * 0.4 - 0.2).contiguous())
         st = int(ts.step_type[0])
-        assert st == (2 if k == 999 else 1), (k, st)
+        assert st == (2 if k == 1000 else 1), (k, st)
         total += float(ts.reward[0])
     assert float(ts.discount[0]) == 1.0 and torch.isfinite(env.flat_observation).all()
     assert 0.0 < total / 1000 < 1.0
@@ -277,8 +303,8 @@ def test_config1_single_env_1000_random_steps(torch_mod):
 
 
 def test_full_episode_soak_batch_1024(torch_mod):
-    """A whole 2.0 s episode (1000 control steps = 10 000 contact-solving substeps) of 1024 envs under random actions, across
-    the time-limit reset: every observation finite, rewards in [0, 1], all envs reach LAST together at step 1000 and FIRST on
+    """A whole 2.0 s episode (1001 control steps = 10 010 contact-solving substeps) of 1024 envs under random actions, across
+    the time-limit reset: every observation finite, rewards in [0, 1], all envs reach LAST together at step 1001 and FIRST on
     the next call, contact counts within capacity, and the capacity-overflow flag (column 7 of the task state) never raised."""
     from flybody_amd import fly_envs
 
@@ -292,17 +318,17 @@ def test_full_episode_soak_batch_1024(torch_mod):
     finite = torch.ones((), dtype=torch.bool, device="cuda")
     overflow = torch.zeros(B, dtype=torch.int32, device="cuda")
     maxcon = torch.zeros(B, dtype=torch.int32, device="cuda")
-    for k in range(1000):
+    for k in range(1001):
         ts = env.step(acts[k % 32])
         rsum += ts.reward
         finite &= torch.isfinite(env.flat_observation).all() & torch.isfinite(ts.reward).all()
-        if k % 50 == 49 or k == 999:
+        if k % 50 == 49 or k == 1000:
             ints, _ = env.get_task_state()
             overflow |= ints[:, 7]
             maxcon = torch.maximum(maxcon, ints[:, 5])
     assert bool(finite)
     assert (ts.step_type == 2).all() and (ts.discount == 1.0).all()
-    assert float(rsum.min()) >= 0.0 and float(rsum.max()) <= 1000.0 and 0.0 < float(rsum.mean()) / 1000 < 1.0
+    assert float(rsum.min()) >= 0.0 and float(rsum.max()) <= 1001.0 and 0.0 < float(rsum.mean()) / 1001 < 1.0
     assert int(overflow.max()) == 0, f"{int((overflow != 0).sum())} envs overflowed the contact / row capacity"
     assert 1 <= int(maxcon.max()) <= 10
     ts = env.step(acts[0])
@@ -329,7 +355,53 @@ def test_actor_loop_with_torch_policy(torch_mod):
         return torch.maximum(torch.minimum(torch.tanh(obs @ W) * 0.2, hi_t), lo_t)
 
     loop = BatchedActorLoop(env, policy)
-    stats = loop.run(1001)  # one full 2.0 s episode of every env plus the first step of the next
-    assert stats["episodes"] == B and abs(stats["episode_length"] - 1000.0) < 1e-6
-    assert 0.0 <= stats["episode_return"] <= 1000.0 and stats["steps_per_second"] > 0
+    stats = loop.run(1002)  # one full 2.0 s episode (1001 control steps) of every env plus the first step of the next
+    assert stats["episodes"] == B and abs(stats["episode_length"] - 1001.0) < 1e-6
+    assert 0.0 <= stats["episode_return"] <= 1001.0 and stats["steps_per_second"] > 0
+    env.close()
+
+
+def test_canonical_action_wrapper_folded_in(torch_mod):
+    """walk_on_ball with canonical_actions=True == the raw env fed canonical2real(a) (tasks/task_utils.py:53-76; acme
+    CanonicalSpecWrapper as applied at train_dmpo_ray.py:128-129); the spec then spans [-1, 1]."""
+    from flybody_amd.batched_env import BatchedBallEnv
+
+    torch = torch_mod
+    B = 16
+    raw = BatchedBallEnv(batch_size=B)
+    can = BatchedBallEnv(batch_size=B, canonical_actions=True, clip_actions=True)
+    spec = can.action_spec()
+    assert (spec.minimum == -1).all() and (spec.maximum == 1).all() and spec.shape == (59,)
+    lo, hi = raw.raw_action_bounds()
+    assert (hi > lo).all()
+    raw.reset(); can.reset()
+    rng = np.random.RandomState(0)
+    for _ in range(5):
+        a = rng.uniform(-1.3, 1.3, (B, 59)).astype(np.float32)              # some entries need the clip
+        real = (lo + np.float32(0.5) * (np.clip(a, -1, 1) + np.float32(1)) * (hi - lo)).astype(np.float32)   # the kernel's float32 expression
+        t0 = raw.step(torch.tensor(real, device="cuda"))
+        o0 = raw.flat_observation.clone()
+        t1 = can.step(torch.tensor(a, device="cuda"))
+        assert torch.equal(o0, can.flat_observation)     # same float32 controls -> same bits
+        assert torch.equal(t0.reward, t1.reward) and torch.equal(t0.step_type, t1.step_type)
+    raw.close(); can.close()
+
+
+def test_reset_envs_restarts_a_subset_only(torch_mod):
+    from flybody_amd.batched_env import BatchedBallEnv
+
+    torch = torch_mod
+    env = BatchedBallEnv(batch_size=6)
+    first = env.reset()
+    obs_first = env.flat_observation.clone()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(4):
+        ts = env.step((torch.rand(6, 59, device="cuda", generator=g) * 0.4 - 0.2).contiguous())
+    before = env.flat_observation.clone()
+    mask = torch.tensor([0, 1, 0, 0, 1, 0], dtype=torch.bool, device="cuda")
+    ts = env.reset_envs(mask)
+    assert torch.equal(env.flat_observation[~mask], before[~mask]) and torch.equal(env.flat_observation[mask], obs_first[mask])
+    assert ts.step_type.tolist() == [1, 0, 1, 1, 0, 1]
+    ints, _ = env.get_task_state()
+    assert ints[:, 2].tolist() == [4, 0, 4, 4, 0, 4]
     env.close()

@@ -71,7 +71,9 @@ def test_device_quaternion_helpers(torch_mod, golden_quat):
     assert _scaled_err(run(0, q1, q2), g["mult_quat"]) < 2e-6
     assert _scaled_err(run(1, q1, q1), g["reciprocal_quat"]) < 2e-6
     assert _scaled_err(run(2, v4, u1)[:, :3], g["rotate_vec_with_quat"]) < 3e-6
-    assert np.max(np.abs(run(3, u1, u2)[:, 0] - g["quat_dist_short_arc"])) < 2e-3  # acos near 0/pi amplifies float32 rounding
+    # the kernel takes the angle as 2 atan2(|vec|, |w|) of the relative quaternion (fly_env.hip quat_dist_short_arc), which is
+    # well conditioned at 0 and pi: the only error left is the float32 rounding of the inputs
+    assert np.max(np.abs(run(3, u1, u2)[:, 0] - g["quat_dist_short_arc"])) < 1e-5
     assert _scaled_err(run(4, u1, u2), g["get_dquat_local"]) < 2e-6
     assert np.isfinite(run(3, u1, u1)).all()
 
@@ -308,9 +310,7 @@ def _mk(torch_mod, wb_tables, rq, rv, B, **kw):
 
     env = BatchedFlyEnv(wb_tables, rq, rv, batch_size=B, seed=9, **kw)
     om = O.OracleModel(BLOB)
-    okw = {k: v for k, v in kw.items() if k in ("future_steps", "terminal_com_dist")}
-    if "time_limit" in kw:
-        okw["time_limit_steps"] = int(round(kw["time_limit"] / wb_tables.dt_ctrl))
+    okw = {k: v for k, v in kw.items() if k in ("future_steps", "terminal_com_dist", "time_limit")}
     oenvs = [O.OracleFlightEnv(om, wb_tables, rq, rv, ghost_accel_z=env.ghost_accel_z, seed=9, env_id=i, **okw) for i in range(B)]
     return env, oenvs
 
@@ -382,7 +382,7 @@ def test_trajectory_end_is_a_good_termination(torch_mod, wb_tables, ref_traj):
 def test_time_limit_termination(torch_mod, wb_tables, ref_traj):
     torch = torch_mod
     env, oenvs = _mk(torch_mod, wb_tables, *ref_traj, B=2, terminal_com_dist=1e9, time_limit=10 * 2e-4 + 14 * 2e-4)
-    # time_limit_steps = 24 > traj_timesteps = 24 - 6 = 18: the trajectory-end rule fires first at 18, as in the reference
+    # round(time_limit / dt) = 24 caps traj_timesteps at 24 - 6 = 18: the trajectory-end rule fires first at 18, as in the reference
     env.reset()
     for e in oenvs:
         e.reset()
@@ -526,3 +526,193 @@ def test_full_batch_conservation_laws(torch_mod, wb_tables, ref_traj):
     assert worst_gpu < 5e-3       # first-order integrator truncation, same order as the oracle's
     assert worst_gap < 2e-5       # float32 vs float64 on the same trajectory
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------- round 2: horizon, shards, ragged sets
+def test_open_loop_1000_steps_full_range_at_bench_batch(torch_mod, wb_tables):
+    """north_star: "per-step reward within 1e-4 of reference over 1000 steps", on the benchmarked workload: the
+    `configs[3]` env exactly as `bench.py` builds it (B = 8192, 64 synthetic trajectories, seed 0) driven open loop by
+    full-range U(lo, hi) actions for 1000 control steps (reference loop: agents/ray_distributed_dmpo.py:401-404).  A 256-env
+    sample (every 32nd env) is twinned with the float64 oracle; nothing is resynchronised except by the episodes' own
+    resets.  An env whose LAST/MID decision differs from the oracle's (a termination threshold crossed within float32
+    rounding) leaves the comparison; the count is reported and bounded."""
+    from flybody_amd import fly_envs
+    from flybody_amd.tasks.synthetic import flight_trajectories
+    from flybody_amd.tasks.trajectories import preprocess
+    from oracle import oracle as O
+
+    torch = torch_mod
+    B, S, STEPS = 8192, 256, 1000
+    env = fly_envs.flight_imitation(batch_size=B, random_state=0)
+    rq, rv = preprocess(*flight_trajectories())
+    om = O.OracleModel(BLOB)
+    sample = np.arange(0, B, B // S)
+    oenvs = [O.OracleFlightEnv(om, wb_tables, rq, rv, ghost_accel_z=env.ghost_accel_z, seed=0, env_id=int(i)) for i in sample]
+    lo = torch.tensor(env.action_spec().minimum, device="cuda")
+    hi = torch.tensor(env.action_spec().maximum, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(77)
+    idx = torch.tensor(sample, device="cuda")
+    env.reset()
+    for e in oenvs:
+        e.reset()
+    alive = np.ones(S, bool)
+    worst, worst_at, compared, pos, resets = 0.0, None, 0, 0, 0
+    err_by_age = np.zeros(STEPS + 1)
+    age = np.zeros(S, int)
+    for k in range(STEPS):
+        a = (lo + (hi - lo) * torch.rand(B, 12, device="cuda", generator=g)).contiguous()
+        ts = env.step(a)
+        a_s = a[idx].cpu().numpy().astype(np.float64)
+        rew, disc, st = ts.reward[idx].cpu().numpy(), ts.discount[idx].cpu().numpy(), ts.step_type[idx].cpu().numpy()
+        for j in range(S):
+            if not alive[j]:
+                continue
+            ost, orr, od, _ = oenvs[j].step(a_s[j])
+            if ost != st[j]:
+                alive[j] = False
+                continue
+            assert od == disc[j]
+            age[j] = 0 if ost == 0 else age[j] + 1
+            compared += 1; pos += int(orr > 0); resets += int(ost == 0)
+            e = abs(float(rew[j]) - orr)
+            err_by_age[age[j]] = max(err_by_age[age[j]], e)
+            if e > worst:
+                worst, worst_at = e, (k, int(sample[j]), age[j])
+    dropped = int((~alive).sum())
+    longest = int(np.nonzero(err_by_age)[0].max()) if err_by_age.any() else 0
+    print(f"open loop, full-range actions, {STEPS} control steps x {S} of {B} envs: compared {compared} env-steps ({pos} with reward > 0, "
+          f"{resets} episode starts, longest episode {longest} steps), max |reward err| {worst:.3e} at (step, env, episode step) {worst_at}, "
+          f"dropped {dropped} envs on a differing LAST/MID decision")
+    assert torch.isfinite(env.flat_observation).all()
+    assert compared > 0.9 * S * STEPS and pos > 0.3 * compared and resets > S
+    assert worst <= 1e-4                      # BASELINE.json north_star tolerance
+    assert dropped <= S // 20                 # termination thresholds crossed within float32 rounding are rare
+    env.close()
+
+
+def test_shards_reproduce_the_single_handle(torch_mod, wb_tables, ref_traj):
+    """BASELINE configs[4] shards the batch over ranks by `env_id_base` (flybody_amd/distributed.py): two handles of B/2
+    with bases 0 and B/2 must give bit-identical (obs, reward, discount, step_type) to one handle of B, across resets."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+
+    torch = torch_mod
+    B, H = 512, 256
+    full = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=6)
+    parts = [BatchedFlyEnv(wb_tables, *ref_traj, batch_size=H, seed=6, env_id_base=b) for b in (0, H)]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lo, hi = (torch.tensor(x, device="cuda") for x in full.raw_action_bounds())
+    t_full = full.reset()
+    t_parts = [p.reset() for p in parts]
+    n_first = 0
+    for k in range(200):
+        if k:
+            a = (lo + (hi - lo) * torch.rand(B, 12, device="cuda", generator=g)).contiguous()
+            t_full = full.step(a)
+            t_parts = [p.step(a[i * H:(i + 1) * H].contiguous()) for i, p in enumerate(parts)]
+            n_first += int((t_full.step_type == 0).sum())
+        for i, (p, t) in enumerate(zip(parts, t_parts)):
+            sl = slice(i * H, (i + 1) * H)
+            assert torch.equal(p.flat_observation, full.flat_observation[sl]), (k, i)
+            assert torch.equal(t.reward, t_full.reward[sl]) and torch.equal(t.discount, t_full.discount[sl])
+            assert torch.equal(t.step_type, t_full.step_type[sl])
+    assert n_first > B  # every env went through at least one auto-reset on average
+    for e in (full, *parts):
+        e.close()
+
+
+def test_trajectories_of_different_lengths(torch_mod, wb_tables, ref_traj):
+    """The reference serves trajectories of individual lengths (trajectory_loaders.py:98-100) and ends an episode at
+    min(len(traj), round(time_limit / dt)) - (future_steps + 1) of the trajectory it drew (flight_imitation.py:107-108):
+    two trajectories of 20 and 31 rows give their good-termination LAST (discount 1) on steps 14 and 25."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+    from flybody_amd.tasks.trajectories import RefSet
+    from oracle import oracle as O
+
+    torch = torch_mod
+    rq, rv = ref_traj
+    lens = [20, 31, 26]
+    refs = RefSet(np.concatenate([rq[i, :n] for i, n in enumerate(lens)]), np.concatenate([rv[i, :n] for i, n in enumerate(lens)]),
+                  np.concatenate(([0], np.cumsum(lens))))
+    B = 6
+    env = BatchedFlyEnv(wb_tables, refs, batch_size=B, seed=9, terminal_com_dist=1e9)
+    om = O.OracleModel(BLOB)
+    oenvs = [O.OracleFlightEnv(om, wb_tables, refs, ghost_accel_z=env.ghost_accel_z, seed=9, env_id=i, terminal_com_dist=1e9) for i in range(B)]
+    traj = np.array([0, 1, 2, 0, 1, 2])
+    env.set_next_trajectory_index(traj, np.full(B, 0.3))
+    env.reset()
+    for i, e in enumerate(oenvs):
+        e.force_next(int(traj[i]), 0.3); e.reset()
+    a = np.zeros((B, 12), np.float32)
+    last_step = {}
+    for k in range(1, 30):
+        ts = env.step(torch.tensor(a, device="cuda"))
+        st, disc = ts.step_type.cpu().numpy(), ts.discount.cpu().numpy()
+        obs = env.flat_observation.cpu().numpy().astype(np.float64)
+        for i, e in enumerate(oenvs):
+            ost, orr, od, oo = e.step(a[i].astype(np.float64))
+            assert (ost, od) == (st[i], disc[i]), (k, i)
+            if ost != 0:
+                assert _obs_err(obs[i], oo) < TOL_OBS_1STEP, (k, i)   # the reference rows are read through the right offsets
+            if st[i] == 2 and i not in last_step:
+                last_step[i] = (k, float(disc[i]))
+    assert [last_step[i] for i in range(3)] == [(14, 1.0), (25, 1.0), (20, 1.0)]
+    assert last_step[3] == last_step[0] and last_step[4] == last_step[1]
+    env.close()
+    with pytest.raises(RuntimeError, match="too short"):   # an episode needs future_steps + 2 rows
+        BatchedFlyEnv(wb_tables, RefSet(rq[0, :6], rv[0, :6], [0, 6]), batch_size=1)
+
+
+def test_reset_envs_restarts_a_subset_only(torch_mod, wb_tables, ref_traj):
+    """ffe_reset_envs: the masked envs start a new episode (FIRST, matching the oracle's reset), the others keep state,
+    counters and output rows bit for bit."""
+    torch = torch_mod
+    env, oenvs = _mk(torch_mod, wb_tables, *ref_traj, B=8)
+    env.reset()
+    for e in oenvs:
+        e.reset()
+    rng = np.random.RandomState(4)
+    for _ in range(5):
+        a = rng.uniform(-0.3, 0.3, (8, 12)).astype(np.float32)
+        ts = env.step(torch.tensor(a, device="cuda"))
+        for i, e in enumerate(oenvs):
+            e.step(a[i].astype(np.float64))
+    before_obs, before_rew = env.flat_observation.clone(), ts.reward.clone()
+    q0, v0 = env.get_state()
+    mask = torch.tensor([1, 0, 0, 1, 0, 1, 0, 0], dtype=torch.bool, device="cuda")
+    ts = env.reset_envs(mask)
+    q1, v1 = env.get_state()
+    keep = ~mask
+    assert torch.equal(env.flat_observation[keep], before_obs[keep]) and torch.equal(ts.reward[keep], before_rew[keep])
+    assert torch.equal(q1[keep], q0[keep]) and torch.equal(v1[keep], v0[keep])
+    assert (ts.step_type[mask] == 0).all() and (ts.step_type[keep] == 1).all()
+    obs = env.flat_observation.cpu().numpy().astype(np.float64)
+    for i in np.nonzero(mask.cpu().numpy())[0]:
+        st, r, d, o = oenvs[i].reset()
+        assert _obs_err(obs[i], o) < TOL_OBS_1STEP
+    # both sides continue in step: the untouched envs are mid-episode, the reset ones at step 1
+    a = rng.uniform(-0.3, 0.3, (8, 12)).astype(np.float32)
+    ts = env.step(torch.tensor(a, device="cuda"))
+    rew = ts.reward.cpu().numpy()
+    for i, e in enumerate(oenvs):
+        ost, orr, od, _ = e.step(a[i].astype(np.float64))
+        assert ost == 1 and abs(orr - rew[i]) < TOL_REWARD_OPEN_100
+    env.close()
+
+
+def test_double_buffered_outputs_keep_the_previous_timestep(torch_mod, wb_tables, ref_traj):
+    """acme's adders keep the previous TimeStep (`observe(action, next_timestep)`): with double_buffer=True the tensors
+    returned by call k stay valid until call k + 2; the default single set is overwritten in place (documented)."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+
+    torch = torch_mod
+    for db in (False, True):
+        env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=4, seed=1, double_buffer=db)
+        t0 = env.reset()
+        snap = {k: v.clone() for k, v in t0.observation.items()}
+        t1 = env.step(torch.full((4, 12), 0.1, device="cuda"))
+        same = all(torch.equal(t0.observation[k], snap[k]) for k in snap)
+        assert same == db and (t0.step_type == 0).all() == db
+        assert not torch.equal(t1.observation["walker/joints_pos"], snap["walker/joints_pos"])
+        with pytest.raises(ValueError):
+            env.step(torch.zeros(4, 12))  # a CPU tensor is not silently copied
+        env.close()

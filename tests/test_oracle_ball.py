@@ -315,7 +315,7 @@ def test_ball_spins_freely_without_contacts_and_fluid(ball):
 
 def test_episode_protocol_time_limit_and_reward(ball):
     m, env = ball
-    env = O.OracleBallEnv(m, time_limit_steps=5)
+    env = O.OracleBallEnv(m, time_limit=0.01)  # 50 float64 additions of 2e-4 reach 0.01: 5 control steps
     assert env.reset()[0] == 0
     d = env.data
     for k in range(5):
@@ -341,4 +341,23 @@ def test_config1_random_actions_stay_finite_and_deterministic(ball):
             tot += r
         outs.append((tot, obs.copy()))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
-    assert env.data.near_unsupported >= 0
+
+
+@pytest.mark.parametrize("time_limit", [0.01, 0.006, 0.0346, 0.05])
+def test_time_limit_is_tested_on_accumulated_physics_time(ball, time_limit):
+    """composer.Environment ends an episode on `physics.time() >= time_limit` with MuJoCo's time a float64 running sum of
+    the physics timestep.  The oracle tests its own accumulated `time`; the host side of the product computes the step count
+    by replaying the additions (`flybody_amd/batched_env.py:time_limit_control_steps`): both must agree, and for the
+    reference's 2.0 s / 0.6 s limits they give 1001 / 3001 control steps, not 1000 / 3000."""
+    from flybody_amd.batched_env import time_limit_control_steps
+
+    m, _ = ball
+    env = O.OracleBallEnv(m, time_limit=time_limit)
+    env.reset()
+    n = 0
+    while True:
+        n += 1
+        if env.step(np.zeros(59))[0] == 2:
+            break
+    assert n == time_limit_control_steps(time_limit, m.timestep, 10)
+    assert time_limit_control_steps(2.0, 2e-4, 10) == 1001 and time_limit_control_steps(0.6, 5e-5, 4) == 3001

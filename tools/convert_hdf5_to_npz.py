@@ -1,39 +1,56 @@
 """Convert a reference flight-trajectory HDF5 file to the `.npz` layout `fly_envs.flight_imitation(ref_path=...)` reads.
 
-The reference stores `trajectories/<zero-padded idx>/{com_qpos (T,7), com_qvel (T,6)}` plus `timestep_seconds`
+The reference stores `trajectories/<zero-padded idx>/{com_qpos (T_i,7), com_qvel (T_i,6)}` plus `timestep_seconds`
 (`vnl_ray/tasks/trajectory_loaders.py:33-35,90-96`).  h5py is not available in the build image, so this runs wherever
 the dataset lives:
 
-    python tools/convert_hdf5_to_npz.py flight-dataset.hdf5 flight-dataset.npz [--min-len 3006]
+    python tools/convert_hdf5_to_npz.py flight-dataset.hdf5 flight-dataset.npz [--min-len 8]
 
-Trajectories are truncated to the shortest kept length so they stack into (N, T, 7) / (N, T, 6).
+Every trajectory keeps its own length (the reference serves them ragged, `trajectory_loaders.py:98-100,124-129`, and
+`flight_imitation.py:107-108` ends an episode by the length of the trajectory it drew): rows are concatenated and
+`traj_off (N+1,)` records where each starts (`flybody_amd/tasks/trajectories.py:save_npz`).
 """
 import argparse
+import os
+import sys
 
-import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def convert(read_group, keys, dt, dst, min_len=8):
+    """`read_group(key) -> (com_qpos, com_qvel)`; split out so the layout logic is testable without h5py."""
+    import numpy as np
+
+    from flybody_amd.tasks.trajectories import save_npz
+
+    qpos, qvel, keep = [], [], []
+    for i, k in enumerate(keys):
+        q, v = read_group(k)
+        q, v = np.asarray(q, dtype=np.float64), np.asarray(v, dtype=np.float64)
+        assert q.ndim == 2 and q.shape[1] == 7 and v.shape == (len(q), 6), (k, q.shape, v.shape)
+        if len(q) >= min_len:
+            qpos.append(q); qvel.append(v); keep.append(i)
+    if not keep:
+        raise SystemExit("no trajectory is long enough")
+    save_npz(dst, qpos, qvel, dt, source_index=np.array(keep))
+    lens = [len(q) for q in qpos]
+    return len(keep), min(lens), max(lens)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("dst")
-    ap.add_argument("--min-len", type=int, default=0, help="drop trajectories shorter than this many steps")
+    ap.add_argument("--min-len", type=int, default=8, help="drop trajectories shorter than this many steps (future_steps + 2 is the minimum an episode needs)")
     args = ap.parse_args()
     import h5py  # noqa: deferred, not installed in the build image
 
     with h5py.File(args.src, "r") as f:
         dt = float(f["timestep_seconds"][()])
-        keys = sorted(f["trajectories"].keys())
-        qpos = [f["trajectories"][k]["com_qpos"][()] for k in keys]
-        qvel = [f["trajectories"][k]["com_qvel"][()] for k in keys]
-    keep = [i for i, q in enumerate(qpos) if len(q) >= max(args.min_len, 8)]
-    if not keep:
-        raise SystemExit("no trajectory is long enough")
-    t = min(len(qpos[i]) for i in keep)
-    np.savez_compressed(args.dst, com_qpos=np.stack([qpos[i][:t] for i in keep]).astype(np.float64),
-                        com_qvel=np.stack([qvel[i][:t] for i in keep]).astype(np.float64), timestep_seconds=np.float64(dt),
-                        source_index=np.array(keep))
-    print(f"wrote {args.dst}: {len(keep)} trajectories x {t} steps @ {dt} s")
+        n = len(f["trajectories"])
+        keys = [str(i).zfill(len(str(n))) for i in range(n)]  # trajectory_loaders.py:91-93
+        n_kept, lo, hi = convert(lambda k: (f["trajectories"][k]["com_qpos"][()], f["trajectories"][k]["com_qvel"][()]), keys, dt, args.dst, args.min_len)
+    print(f"wrote {args.dst}: {n_kept} trajectories, {lo}..{hi} steps @ {dt} s")
 
 
 if __name__ == "__main__":
