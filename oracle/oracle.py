@@ -109,6 +109,13 @@ def lib():
         L.fo_ball_obs_dim.argtypes = [vp]
         L.fo_ball_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_ball_env_hist.argtypes = [vp, ip, dp, C.c_int]
+        L.fo_set_measure_unsupported.argtypes = [vp, C.c_int]
+        L.fo_unsupported_min_sep.restype = C.c_double
+        L.fo_unsupported_min_sep.argtypes = [vp, vp, ip, ip]
+        L.fo_self_min_clear.restype = C.c_double
+        L.fo_self_min_clear.argtypes = [vp, ip, ip]
+        L.fo_convex_separation.restype = C.c_double
+        L.fo_convex_separation.argtypes = [vp, vp, C.c_int, C.c_int, dp]
         L.fo_env_counters.restype = C.c_int
         L.fo_env_counters.argtypes = [vp, ip, ip]
     return _lib
@@ -209,6 +216,19 @@ class OracleData:
         for i in range(self.ncon):
             self.L.fo_contact_info(self.ptr, i, _dp(out[i]))
         return out
+
+    def unsupported_min_sep(self):
+        """(lower bound of the smallest separation among the ellipsoid / cylinder pairs, geom1, geom2); needs
+        `model.L.fo_set_measure_unsupported(model.ptr, 1)`."""
+        g1, g2 = C.c_int(), C.c_int()
+        s = self.L.fo_unsupported_min_sep(self.m.ptr, self.ptr, C.byref(g1), C.byref(g2))
+        return s, g1.value, g2.value
+
+    def self_min_clear(self):
+        """(smallest dist - margin among the sphere / capsule fly-fly candidate pairs that passed the bounding test, geom1, geom2)."""
+        g1, g2 = C.c_int(), C.c_int()
+        s = self.L.fo_self_min_clear(self.ptr, C.byref(g1), C.byref(g2))
+        return s, g1.value, g2.value
 
     @property
     def time(self):

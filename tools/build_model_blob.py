@@ -33,6 +33,15 @@ def main():
     with open(os.path.join(OUT, "fly_flight.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote", OUT, "nbody", m.nbody, "nv", m.nv, "nu", m.nu)
+    # The same flight model with its collision geoms attached: the product kernel carries no flight contacts (the floor is
+    # disabled, tasks/base.py:299-302); this blob lets the oracle measure how close the remaining fly-fly pairs come
+    # (tools/self_collision_stats.py).  Oracle-side asset only.
+    ocol = os.path.join(os.path.dirname(__file__), "..", "oracle", "assets")
+    os.makedirs(ocol, exist_ok=True)
+    write_blob(os.path.join(ocol, "fly_flight_collision.ffmb"), model_tensors(m, L, with_collision=True))
+    with open(os.path.join(ocol, "fly_flight_collision.json"), "w") as f:
+        json.dump({"body_name": m.body_name, "geom_name": m.geom_name}, f, indent=1)
+    print("wrote flight collision blob: ngeom", len(m.geom_bodyid))
     b = build_ball_model()
     write_blob(os.path.join(OUT, "fly_ball.ffmb"), model_tensors(b, with_collision=True))
     meta = {
