@@ -112,6 +112,8 @@ def lib():
         L.fo_set_measure_unsupported.argtypes = [vp, C.c_int]
         L.fo_unsupported_min_sep.restype = C.c_double
         L.fo_unsupported_min_sep.argtypes = [vp, vp, ip, ip]
+        L.fo_unsupported_touching.restype = C.c_int
+        L.fo_unsupported_touching.argtypes = [vp, vp, ip, ip, C.c_int]
         L.fo_self_min_clear.restype = C.c_double
         L.fo_self_min_clear.argtypes = [vp, ip, ip]
         L.fo_convex_separation.restype = C.c_double
@@ -223,6 +225,12 @@ class OracleData:
         g1, g2 = C.c_int(), C.c_int()
         s = self.L.fo_unsupported_min_sep(self.m.ptr, self.ptr, C.byref(g1), C.byref(g2))
         return s, g1.value, g2.value
+
+    def unsupported_touching(self):
+        """[(geom1, geom2)] of the ellipsoid / cylinder pairs whose separation is within their margin (measurement mode)."""
+        g1, g2 = np.zeros(16, dtype=np.int32), np.zeros(16, dtype=np.int32)
+        n = self.L.fo_unsupported_touching(self.m.ptr, self.ptr, _ip(g1), _ip(g2), 16)
+        return n, list(zip(g1[: min(n, 16)].tolist(), g2[: min(n, 16)].tolist()))
 
     def self_min_clear(self):
         """(smallest dist - margin among the sphere / capsule fly-fly candidate pairs that passed the bounding test, geom1, geom2)."""

@@ -53,7 +53,7 @@ def _worker(args):
     env.reset()
     d = env.data
     out = dict(steps=0, selfcon_steps=0, selfcon_max=0, self_min=1e30, self_pair=None, unsup_min=1e30, unsup_pair=None, near_unsup_steps=0,
-               episodes=0)
+               episodes=0, unsup_touch_steps=0, unsup_pairs={}, sup_pairs={}, first_obs_touch=0)
     for _ in range(steps):
         st = env.step(draw())[0]
         out["steps"] += 1
@@ -64,6 +64,8 @@ def _worker(args):
         for row in c:
             if "ball" not in names[int(row[0])] and "ball" not in names[int(row[1])]:
                 nself += 1
+                key = names[int(row[0])] + " | " + names[int(row[1])]
+                out["sup_pairs"][key] = out["sup_pairs"].get(key, 0) + 1
         out["selfcon_steps"] += int(nself > 0)
         out["selfcon_max"] = max(out["selfcon_max"], nself)
         s, g1, g2 = d.self_min_clear()
@@ -73,6 +75,12 @@ def _worker(args):
         if u < out["unsup_min"]:
             out["unsup_min"], out["unsup_pair"] = u, (names[g1], names[g2])
         out["near_unsup_steps"] += int(d.near_unsupported > 0)
+        nt, pairs = d.unsupported_touching()
+        out["unsup_touch_steps"] += int(nt > 0)
+        out["first_obs_touch"] += int(nt > 0 and st == 0)
+        for g1, g2 in pairs:
+            key = names[g1] + " | " + names[g2]
+            out["unsup_pairs"][key] = out["unsup_pairs"].get(key, 0) + 1
     return out
 
 
@@ -99,6 +107,14 @@ def main():
     tot["supported_min_dist_minus_margin_cm"], tot["supported_min_pair"] = b["self_min"], b["self_pair"]
     b = min(res, key=lambda r: r["unsup_min"])
     tot["unsupported_min_separation_lower_bound_cm"], tot["unsupported_min_pair"] = b["unsup_min"], b["unsup_pair"]
+    tot["steps_with_unsupported_pair_within_margin"] = sum(r["unsup_touch_steps"] for r in res)
+    tot["episode_starts_with_unsupported_pair_within_margin"] = sum(r["first_obs_touch"] for r in res)
+    for k in ("unsup_pairs", "sup_pairs"):
+        agg = {}
+        for r in res:
+            for kk, v in r[k].items():
+                agg[kk] = agg.get(kk, 0) + v
+        tot[k + "_steps"] = dict(sorted(agg.items(), key=lambda kv: -kv[1])[:12])
     tot["amp"] = args.amp if args.kind == "ball" else "full action spec"
     tot["wall_s"] = round(time.perf_counter() - t0, 1)
     print(json.dumps(tot))
