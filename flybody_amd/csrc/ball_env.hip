@@ -52,7 +52,7 @@ struct alignas(16) BState {
   float q[NDP], v[NDP], act[64];
   float ballq[4], ballw[4];
   float qacc_ws[NDP], wsc[NL][3];  // warm start of the constraint solver: last limit force per dof, last contact force per link
-  int step_counter, needs_reset, overflow, iters, ncon, have_ws;
+  int step_counter, needs_reset, overflow, iters, ncon, have_ws, nself, pad1;
   unsigned con_hist[2];  // active (inside includemargin) contacts of each of the control step's first 16 substeps, 4 bits each: parity tooling
 };
 
@@ -112,7 +112,8 @@ struct Ctx {
   float mass;
   Q4 bq;
   V3 bw, btau;
-  int nc, nact;           // contacts detected / of those, the ones inside includemargin (they get constraint rows)
+  int nc, nact;           // ball contacts detected / of those, the ones inside includemargin (they get constraint rows)
+  int nsc;                // fly-fly contacts of this substep: slots nc .. nc + nsc - 1 of the contact arrays (see self_collide)
   float wsl[3], wsc[3];   // warm start of the constraint solver: last substep's limit force per slot, contact force of this link
   int have_ws, overflow;
 #ifdef FFB_STAMPS
@@ -353,6 +354,188 @@ __device__ __forceinline__ float impedance(const float *si, float x) {
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
   else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
   return d0 + y * (d1 - d0);
+}
+
+// ------------------------------------------------------------------------------------------------ fly-fly collision
+// mj: mj_collision narrow phase for the fly's own sphere / capsule pairs: mjc_CapsuleCapsule (closest points of the two
+// segments, one contact; a sphere is a capsule of zero length, for which the same formulas reduce to mjc_SphereCapsule /
+// mjraw_SphereSphere).  Broad phase = MuJoCo's bounding-sphere test.  A detected contact (dist <= margin) takes the next
+// free slot of the contact arrays after the ball contacts: c_link = link of geom1 | link of geom2 << 8, c_frame[0..2] =
+// normal from geom1 to geom2, c_par = {K, B, invweight, 0, margin - gap}.  Returns the number of fly-fly contacts stored.
+__device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane, const int nc) {
+  BTile &T = *Tp;
+  const BallModel FFE_GLOBAL &M = *Mp;
+  const float(*pg)[8] = reinterpret_cast<const float(*)[8]>(&T.lk[0][0]);
+  const float mclaw = M.sc_margin;
+  const unsigned long long claws = M.sp_claw;
+  const int sphere = M.sp_sphere;
+  // lane s owns slot s and meets slots s + 1 .. s + NPG / 2 (mod NPG): every unordered pair once
+  const bool own = lane < NPG;
+  const unsigned long long partners = own ? M.sp_mask[lane] : 0ull;
+  const float4 o0 = own ? *reinterpret_cast<const float4 *>(&pg[lane][0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 o1 = own ? *reinterpret_cast<const float4 *>(&pg[lane][4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float oreach = o1.z + o1.w + (((claws >> lane) & 1ull) ? mclaw : 0.f);
+  unsigned near = 0u;  // bit t - 1: the pair (lane, lane + t) passed the bounding-sphere test
+#pragma unroll 4
+  for (int t = 1; t <= NPG / 2; t++) {
+    int j = lane + t;
+    j = j >= NPG ? j - NPG : j;
+    if (own && ((partners >> j) & 1ull) && (t < NPG / 2 || lane < NPG / 2)) {
+      const float4 p0 = *reinterpret_cast<const float4 *>(&pg[j][0]);
+      const float2 p1 = *reinterpret_cast<const float2 *>(&pg[j][6]);
+      const float dx = p0.x - o0.x, dy = p0.y - o0.y, dz = p0.z - o0.z;
+      const float reach = oreach + p1.x + p1.y + mclaw;  // (the claw margin on both sides: a bound is all that is needed here)
+      if (dx * dx + dy * dy + dz * dz <= reach * reach) near |= 1u << (t - 1);
+    }
+  }
+  int nsc = 0, ovf = 0;
+#pragma unroll 1
+  while (__ballot(near != 0u) != 0ull) {
+    bool hit = false;
+    float dist = 0.f, margin = 0.f;
+    V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
+    int s1 = 0, s2 = 0;
+    if (near) {
+      const int t = __ffs(near);
+      near &= near - 1u;
+      int j = lane + t;
+      j = j >= NPG ? j - NPG : j;
+      // mj: geom1 is the one with the lower type code (the sphere), else the one that comes first in the model
+      const bool swap = j == sphere || (lane != sphere && j < lane);
+      s1 = swap ? j : lane; s2 = swap ? lane : j;
+      const float *a = pg[s1], *b = pg[s2];
+      const V3 p1 = {a[0], a[1], a[2]}, a1 = {a[3], a[4], a[5]}, p2 = {b[0], b[1], b[2]}, a2 = {b[3], b[4], b[5]};
+      const float l1 = a[6], r1 = a[7], l2 = b[6], r2 = b[7];
+      margin = (((claws >> s1) | (claws >> s2)) & 1ull) ? mclaw : 0.f;
+      const V3 dif = p1 - p2;
+      const float mb = -dot(a1, a2), u = -dot(a1, dif), v = dot(a2, dif), det = 1.f - mb * mb;
+      float x1, x2;
+      if (fabsf(det) >= 1e-6f) {
+        const float idet = 1.f / det;
+        x1 = (u - mb * v) * idet; x2 = (v - mb * u) * idet;
+        if (x1 > l1) { x1 = l1; x2 = v - mb * l1; } else if (x1 < -l1) { x1 = -l1; x2 = v + mb * l1; }
+        if (x2 > l2) { x2 = l2; x1 = fminf(fmaxf(u - mb * l2, -l1), l1); }
+        else if (x2 < -l2) { x2 = -l2; x1 = fminf(fmaxf(u + mb * l2, -l1), l1); }
+      } else {  // parallel axes: centre of the overlapping stretch
+        const float c2 = u, lo = fmaxf(-l1, c2 - l2), hi = fminf(l1, c2 + l2);
+        x1 = lo <= hi ? 0.5f * (lo + hi) : (c2 > 0.f ? l1 : -l1);
+        x2 = fminf(fmaxf((x1 - c2) * (mb < 0.f ? 1.f : -1.f), -l2), l2);
+      }
+      const V3 q1 = p1 + x1 * a1, q2 = p2 + x2 * a2, d12 = q2 - q1;
+      const float cd = fsqrt(dot(d12, d12));
+      hit = cd <= margin + r1 + r2;
+      if (cd >= 1e-15f) nrm = frcp(cd) * d12;
+      dist = cd - r1 - r2;
+      cpos = q1 + (r1 + 0.5f * dist) * nrm;
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (bal) {
+      const int idx = nc + nsc + __popcll(bal & ((1ull << lane) - 1ull));
+      if (hit && idx < NC) {
+        const float incl = margin - (margin != 0.f ? M.sc_gap : 0.f);
+        T.c_link[idx] = M.pgs_link[s1] | (M.pgs_link[s2] << 8);
+        T.c_excl[idx] = dist >= incl ? 1 : 0;
+        T.c_dist[idx] = dist;
+        T.c_pos[idx][0] = cpos.x; T.c_pos[idx][1] = cpos.y; T.c_pos[idx][2] = cpos.z;
+        T.c_frame[idx][0] = nrm.x; T.c_frame[idx][1] = nrm.y; T.c_frame[idx][2] = nrm.z;
+        T.c_par[idx][0] = M.sc_K; T.c_par[idx][1] = M.sc_B; T.c_par[idx][2] = M.pgs_invw[s1] + M.pgs_invw[s2]; T.c_par[idx][3] = 0.f;
+        T.c_par[idx][4] = incl;
+      }
+      const int n = __popcll(bal);
+      if (nc + nsc + n > NC) ovf = 1;  // more contacts than the tile holds: the extra ones are dropped and the env is flagged
+      nsc = min(nsc + n, NC - nc);
+    }
+  }
+  return nsc | (ovf << 8);
+}
+
+// Fly-fly contact slots keep the dofs of geom2's chain (14 bytes), and the block-local solve column of that chain (byte 14),
+// in the slot's unused ball Jacobian.
+__device__ __forceinline__ unsigned char *sc_chain_b(BTile &T, int k) { return reinterpret_cast<unsigned char *>(&T.c_Jb[k][0][0]); }
+
+// mj: mj_makeConstraint rows of the fly-fly contacts (condim 1: one frictionless row each, J = n . (jacp2 - jacp1) at the
+// contact point), mj_makeImpedance, mj_referenceConstraint; and mj_transmission mjTRN_BODY for the adhesion actuators: an
+// adhesion force is spread evenly over ALL contacts of its body (ball and fly-fly, also the ones inside the gap), which
+// rewrites the weights the ball-only path set.  Slot k = nc + j: c_J[k][0] / c_J[k][1] = the row over the chain dofs of
+// geom1's / geom2's link, c_chain[k] / sc_chain_b = those dofs, c_nch / c_blk = counts / blocks (second << 8),
+// c_amask = chain masks (second << 16), c_adh = adhesion actuators of the two links (255 = none).
+__device__ __noinline__ void self_rows(BTile *Tp, ModelPtr Mp, const int lane, const int nc, const int nsc) {
+  BTile &T = *Tp;
+  const BallModel FFE_GLOBAL &M = *Mp;
+  const V3 c0 = {M.thorax_pos[0], M.thorax_pos[1], M.thorax_pos[2]};
+  for (int j = 0; j < nsc; j++) {
+    const int k = nc + j, la = T.c_link[k] & 255, lb = T.c_link[k] >> 8;
+    const int half = lane >> 4, p = lane & 15, link = half == 0 ? la : lb;
+    const int nch = half < 2 ? M.l_nchain[link] : 0;
+    float jv = 0.f, vv = 0.f;
+    int f = 0;
+    if (half < 2 && p < nch) {
+      f = M.l_chain[p][link];
+      const S6 cd = ld6(T.C[f]);
+      const V3 r = V3{T.c_pos[k][0], T.c_pos[k][1], T.c_pos[k][2]} - c0;
+      const V3 u = lin(cd) + cross(ang(cd), r);
+      jv = (T.c_frame[k][0] * u.x + T.c_frame[k][1] * u.y + T.c_frame[k][2] * u.z) * (half == 0 ? -1.f : 1.f);
+      vv = T.V[f];
+    }
+    if (half < 2 && p < NCH) {
+      T.c_J[k][half][p] = jv;
+      if (half == 0) T.c_chain[k][p] = (unsigned char)f; else sc_chain_b(T, k)[p] = (unsigned char)f;
+    }
+    const float vel = wave_sum(jv * vv);
+    if (lane == 0) {
+      const int na = M.l_nchain[la], nb = M.l_nchain[lb], fa = M.l_chain[na - 1][la], fb = M.l_chain[nb - 1][lb];
+      T.c_nch[k] = na | (nb << 8);
+      T.c_blk[k] = (int)M.d_blk[fa] | ((int)M.d_blk[fb] << 8);
+      T.c_amask[k] = (unsigned)M.d_amask[fa] | ((unsigned)M.d_amask[fb] << 16);
+      T.c_adh[k] = (M.l_adh[la] & 255) | ((M.l_adh[lb] & 255) << 8);
+      const float K = T.c_par[k][0], B = T.c_par[k][1], invw = T.c_par[k][2], incl = T.c_par[k][4], dist = T.c_dist[k];
+      float si_[5];
+#pragma unroll
+      for (int q2 = 0; q2 < 5; q2++) si_[q2] = M.sc_solimp[q2];
+      const float imp = impedance(si_, fabsf(dist - incl));
+      const float R0 = fmaxf(1e-15f, (1.f - imp) * invw * frcp(imp));
+      T.c_D[k] = T.c_excl[k] ? 0.f : frcp(R0);
+      T.c_mu[k] = 0.f;
+      T.c_aref[k][0] = -B * vel - K * imp * (dist - incl);
+      T.c_aref[k][1] = T.c_aref[k][2] = 0.f;
+    }
+  }
+  DM_SYNC();
+  // adhesion weights over all contacts of the claw's body
+  if (lane < nc + nsc) {
+    const int k = lane;
+    auto ids = [&](int kk, int &a1, int &a2) {
+      if (kk < nc) { a1 = T.c_adh[kk] >= 0 ? T.c_adh[kk] : 255; a2 = 255; }
+      else { a1 = T.c_adh[kk] & 255; a2 = (T.c_adh[kk] >> 8) & 255; }
+    };
+    int a1, a2;
+    ids(k, a1, a2);
+    int n1 = 0, n2 = 0;
+    for (int kk = 0; kk < nc + nsc; kk++) {
+      int b1, b2;
+      ids(kk, b1, b2);
+      n1 += (a1 != 255 && (b1 == a1 || b2 == a1)) ? 1 : 0;
+      n2 += (a2 != 255 && (b1 == a2 || b2 == a2)) ? 1 : 0;
+    }
+    float w = 0.f;
+    if (a1 != 255) w -= T.frc[a1] / (float)n1;
+    if (a2 != 255 && a2 != a1) w -= T.frc[a2] / (float)n2;
+    T.c_w[k][0] = w; T.c_w[k][1] = 0.f; T.c_w[k][2] = 0.f;
+  }
+  DM_SYNC();
+}
+
+// sum over the fly-fly contacts whose row touches fly dof (blk, li) of J[c][p] * w[c][0]
+__device__ __forceinline__ float self_gather(const Ctx &c, unsigned sbl, const float (*w)[3]) {
+  const BTile &T = *c.T;
+  const unsigned li = sbl >> 8, blk = sbl & 0xffu;
+  float acc = 0.f;
+  for (int k = c.nc; k < c.nc + c.nsc; k++) {
+    const unsigned bl = (unsigned)T.c_blk[k], am = T.c_amask[k];
+    if ((bl & 0xffu) == blk && ((am >> li) & 1u)) acc += T.c_J[k][0][__popc(am & 0xffffu & ((1u << li) - 1u))] * w[k][0];
+    if ((bl >> 8) == blk && ((am >> (16 + li)) & 1u)) acc += T.c_J[k][1][__popc((am >> 16) & ((1u << li) - 1u))] * w[k][0];
+  }
+  return acc;
 }
 
 // ------------------------------------------------------------------------------------------------ stage 1
@@ -601,6 +784,28 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     unsigned bm = 0u;
     for (int k = 0; k < c.nc; k++) if (T.c_blk[k] == lane) bm |= 1u << k;
     T.c_bmask[lane] = bm;
+  }
+  // ---- mj: mj_collision over the fly's own sphere / capsule pairs (condim 1).  Every link publishes its primitive geoms
+  //      (world centre, axis, half length, radius) into the link-exchange area, which is free between the factorisation and
+  //      stage 2; the pair tests read them back from there.
+  c.nsc = 0;
+  if (!(c.flags & BF_NO_CONTACT)) {
+    float(*pg)[8] = reinterpret_cast<float(*)[8]>(&T.lk[0][0]);
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const int slot = M.pg_slot[w][lane];
+      if (slot >= 0) {
+        const V3 gc = c.xp + mv(xmat, V3{M.pg_pos[w][0][lane], M.pg_pos[w][1][lane], M.pg_pos[w][2][lane]});
+        const V3 ga = mv(xmat, V3{M.pg_axis[w][0][lane], M.pg_axis[w][1][lane], M.pg_axis[w][2][lane]});
+        float *o = pg[slot];
+        o[0] = gc.x; o[1] = gc.y; o[2] = gc.z; o[3] = ga.x; o[4] = ga.y; o[5] = ga.z; o[6] = M.pg_half[w][lane]; o[7] = M.pg_rad[w][lane];
+      }
+    }
+    DM_SYNC();
+    const int sc = self_collide(c.T, (ModelPtr)c.M, lane, c.nc);
+    c.nsc = sc & 0xff;
+    if (sc >> 8) c.overflow = 1;
+    for (int k = c.nc; k < c.nc + c.nsc; k++) c.nact += T.c_excl[k] ? 0 : 1;
   }
   DM_SYNC();
   BSTAMP(5);  // collision
@@ -988,6 +1193,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
   }
   DM_SYNC();
+  const int nsc = c.nsc;
+  if (nsc) self_rows(c.T, (ModelPtr)c.M, lane, nc, nsc);  // fly-fly contacts (rare): rows, impedance, adhesion shares
   BSTAMP(6);  // actuation + contact rows
   // ---- smooth forces (mj: mj_fwdAcceleration); the smooth acceleration a_s = M^-1 qfrc_smooth rides as column 0 of the
   //      first block solve of the G build below
@@ -1001,6 +1208,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       if (a0 >= 0) f += M.s_actcoef[0][s][lane] * T.frc[a0];
       if (a1 >= 0) f += M.s_actcoef[1][s][lane] * T.frc[a1];
       if (nc) f += contact_gather(c, opq(c.sbl[s]), T.c_w);
+      if (nsc) f += self_gather(c, opq(c.sbl[s]), T.c_w);
       qs[s] = f;
     }
   }
@@ -1039,6 +1247,15 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   int lrow[3] = {-1, -1, -1};
   const int nrc = 3 * nc;
   int R = nrc;
+  if (nsc) {  // fly-fly contact rows: one unilateral row each (condim 1), handled by the solver like a joint-limit row
+    if (lane < nsc) {
+      const int row = nrc + lane, k = nc + lane;
+      T.r_sgn[row] = 0.f; T.r_D[row] = T.c_D[k]; T.r_dof[row] = (unsigned char)k; T.r_blk[row] = (unsigned char)(T.c_blk[k] & 0xff);
+      T.r_y0[row] = -T.c_aref[k][0];
+      T.r_lam[row] = 0.f;
+    }
+    R += nsc;
+  }
   {  // limit rows: one per instantiated limit, in (slot, lane) order; y0 starts as -aref, J a_s is added by the first solve
 #pragma unroll
     for (int s = 0; s < 3; s++) {
@@ -1070,20 +1287,30 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   // columns: a row's column is its rank among the rows of its block
   int ncol;
   {
-    int mycol = 0;
+    int mycol = 0, mycol2 = 0;
     const int myb = lane < R ? (int)T.r_blk[lane] : -1;
+    int myb2 = -1;  // a fly-fly row whose two chains sit in different blocks needs a column in each of them
+    if (nsc && lane >= nrc && lane < nrc + nsc) { myb2 = T.c_blk[nc + lane - nrc] >> 8; if (myb2 == myb) myb2 = -1; }
     for (int b = 0; b < NBLK; b++) {  // rank among the lower rows of the same block, by ballots
-      const unsigned long long mb = __ballot(myb == b);
+      const unsigned long long mb = __ballot(myb == b || myb2 == b);
       if (myb == b) mycol = __popcll(mb & ((1ull << lane) - 1ull));
+      if (myb2 == b) mycol2 = __popcll(mb & ((1ull << lane) - 1ull));
     }
     if (lane < R) {
       const int b = myb;
       T.r_col[lane] = (unsigned char)mycol;
-      if (mycol < 12) T.rowof[b][mycol] = (unsigned char)lane; else c.overflow = 1;
+      if (mycol < 12) T.rowof[b][mycol] = (unsigned char)lane;
+      if (myb2 >= 0) {
+        sc_chain_b(T, nc + lane - nrc)[14] = (unsigned char)mycol2;
+        if (mycol2 < 12) T.rowof[myb2][mycol2] = (unsigned char)lane;
+        mycol = max(mycol, mycol2);
+      } else if (nsc && lane >= nrc && lane < nrc + nsc) sc_chain_b(T, nc + lane - nrc)[14] = (unsigned char)mycol;
       mycol += 1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mycol = max(mycol, __shfl_xor(mycol, off));
+    if (mycol > 12) c.overflow = 1;  // more than 12 rows in one block of M (e.g. five ball contacts on one leg): the extra rows are
+                                     // dropped and the env is flagged (wave-uniform here: lane 0 reports it)
     ncol = min(mycol, 12);
   }
   DM_SYNC();
@@ -1111,9 +1338,24 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       const int r = item / NCH, p = item - r * NCH, k = r / 3, col = (int)T.r_col[r] + 1 - cb;
       if (col >= 0 && col < 4 && p < T.c_nch[k]) (&T.X4[T.c_chain[k][p]].x)[col] = T.c_J[k][r - 3 * k][p];
     }
-    if (lane >= nrc && lane < R) {
+    if (lane >= nrc + nsc && lane < R) {
       const int col = (int)T.r_col[lane] + 1 - cb;
       if (col >= 0 && col < 4) (&T.X4[T.r_dof[lane]].x)[col] = T.r_sgn[lane];
+    }
+    if (nsc) {  // fly-fly rows: J' over geom1's chain, then (the chains may share dofs) accumulated over geom2's chain
+#pragma unroll 1
+      for (int half = 0; half < 2; half++) {
+        DM_SYNC();
+        for (int item = lane; item < nsc * 16; item += 64) {
+          const int j = item >> 4, p = item & 15, k = nc + j;
+          const int nch = (T.c_nch[k] >> (8 * half)) & 0xff;
+          const int col = (half == 0 ? (int)T.r_col[nrc + j] : (int)sc_chain_b(T, k)[14]) + 1 - cb;
+          if (p < nch && col >= 0 && col < 4) {
+            const int f = half == 0 ? (int)T.c_chain[k][p] : (int)sc_chain_b(T, k)[p];
+            (&T.X4[f].x)[col] += T.c_J[k][half][p];
+          }
+        }
+      }
     }
     DM_SYNC();
     solve4(c, T.Lm, T.dinv_m);
@@ -1127,6 +1369,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         const int k = lane / 3, r = lane - 3 * k, nch = T.c_nch[k];
         for (int p = 0; p < nch; p++) {
           const float jv = T.c_J[k][r][p];
+          const float4 y = T.X4[T.c_chain[k][p]];
+          acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
+        }
+      } else if (lane < nrc + nsc) {  // fly-fly row: geom1's chain here, geom2's chain below
+        const int k = nc + lane - nrc, nch = T.c_nch[k] & 0xff;
+        for (int p = 0; p < nch; p++) {
+          const float jv = T.c_J[k][0][p];
           const float4 y = T.X4[T.c_chain[k][p]];
           acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
         }
@@ -1144,6 +1393,25 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         else if (gc - 1 < 12) {
           const int r2 = T.rowof[b][gc - 1];
           if (r2 <= lane) T.G[gtri + r2] += av;  // (255 = no such row)
+        }
+      }
+      if (nsc && lane >= nrc && lane < nrc + nsc) {  // second chain of a fly-fly row, against the columns of its own block
+        const int k = nc + lane - nrc, nch = (T.c_nch[k] >> 8) & 0xff, b2 = T.c_blk[k] >> 8;
+        float4 ac2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < nch; p++) {
+          const float jv = T.c_J[k][1][p];
+          const float4 y = T.X4[sc_chain_b(T, k)[p]];
+          ac2.x += jv * y.x; ac2.y += jv * y.y; ac2.z += jv * y.z; ac2.w += jv * y.w;
+        }
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++) {
+          const int gc = cb + q2;
+          const float av = q2 == 0 ? ac2.x : (q2 == 1 ? ac2.y : (q2 == 2 ? ac2.z : ac2.w));
+          if (gc == 0) T.r_y0[lane] += av;
+          else if (gc - 1 < 12) {
+            const int r2 = T.rowof[b2][gc - 1];
+            if (r2 <= lane) T.G[gtri + r2] += av;
+          }
         }
       }
     }
@@ -1170,6 +1438,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   BSTAMP(16);  // noslip
   // ---- constraint forces in joint space, final acceleration a = a_s + M^-1 J' f
   if (lane < nrc) T.c_f[lane / 3][lane % 3] = constrained ? T.r_f[lane] : 0.f;
+  if (nsc && lane < nsc) { T.c_f[nc + lane][0] = T.r_f[nrc + lane]; T.c_f[nc + lane][1] = 0.f; T.c_f[nc + lane][2] = 0.f; }
   DM_SYNC();
   float qc[3], a[3];
 #pragma unroll
@@ -1178,6 +1447,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     if (slot_on(c, s)) {
       if (lrow[s] >= 0) { const float lf_ = T.r_f[lrow[s]]; qc[s] = lsgn[s] * lf_; c.wsl[s] = lf_; } else c.wsl[s] = 0.f;
       if (nc) qc[s] += contact_gather(c, opq(c.sbl[s]), T.c_f);
+      if (nsc) qc[s] += self_gather(c, opq(c.sbl[s]), T.c_f);
     }
   }
   c.wsc[0] = c.wsc[1] = c.wsc[2] = 0.f;
@@ -1226,6 +1496,14 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         const float f0 = T.c_f[k][0], f1 = T.c_f[k][1], f2 = T.c_f[k][2];
         fext = fext + V3{fr[0] * f0 + fr[3] * f1 + fr[6] * f2, fr[1] * f0 + fr[4] * f1 + fr[7] * f2, fr[2] * f0 + fr[5] * f1 + fr[8] * f2};
         if (f0 > 0.f) touch += f0;
+      }
+    }
+    for (int k = nc; k < nc + nsc; k++) {  // fly-fly contacts: -n f on geom1's link, +n f on geom2's (mj_rnePostConstraint's cfrc_ext)
+      const int la = T.c_link[k] & 255, lb = T.c_link[k] >> 8;
+      if ((la == lane || lb == lane) && !T.c_excl[k]) {
+        const float f0 = T.c_f[k][0] * (lb == lane ? 1.f : -1.f);
+        fext = fext + V3{T.c_frame[k][0] * f0, T.c_frame[k][1] * f0, T.c_frame[k][2] * f0};
+        if (T.c_f[k][0] > 0.f) touch += T.c_f[k][0];  // the contact point lies inside the claw's (larger) touch site
       }
     }
     S6 dacc = zero6();  // sum over the dofs of the ancestor path of cdof * qacc (path sum by pointer jumping, as in stage 1)
@@ -1379,7 +1657,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   if (lane == 0) {
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
-    S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc;
+    S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc + c.nsc; S.nself = c.nsc;
     S.con_hist[0] = (unsigned)con_hist; S.con_hist[1] = (unsigned)(con_hist >> 32);
     cost[env] = iters;  // key of the next launch's order: Newton iterations over this step's substeps, what the launch time varies with
     if (do_reset) S.overflow = 0; else if (c.overflow) S.overflow = 1;
@@ -1477,7 +1755,7 @@ __global__ void ball_task_state_kernel(const BState *states, int *ints, double *
   if (i >= batch) return;
   const BState &S = states[i];
   int *o = ints + (size_t)i * 8;
-  o[0] = (int)S.con_hist[0]; o[1] = (int)S.con_hist[1]; o[2] = S.step_counter; o[3] = 0; o[4] = S.needs_reset; o[5] = S.ncon; o[6] = S.iters; o[7] = S.overflow;
+  o[0] = (int)S.con_hist[0]; o[1] = (int)S.con_hist[1]; o[2] = S.step_counter; o[3] = S.nself; o[4] = S.needs_reset; o[5] = S.ncon; o[6] = S.iters; o[7] = S.overflow;
   for (int k = 0; k < 8; k++) reals[(size_t)i * 8 + k] = 0.0;
 }
 

@@ -48,6 +48,7 @@ constexpr int NACT = 59;
 constexpr int MAXDEPTH = 8;
 constexpr int NFS = 56;     // slots of the factorisation schedule (64 entry updates per slot)
 constexpr int NPS = 24;     // slots of each triangular-solve schedule
+constexpr int NPG = 48;     // sphere / capsule collision geoms on fly links ("primitive geoms": legs 42, mouth 3, antennae 2, abdomen_7)
 
 struct BallModel {
   // ---- options
@@ -104,6 +105,18 @@ struct BallModel {
   unsigned l_tree[NL];              // subtree size (links are in depth-first order: the subtree of l is lanes l .. l + size - 1)
                                     // | (ancestor 2 levels up) + 1 << 8 | (ancestor 4 levels up) + 1 << 16
   int maxsub;                       // largest subtree size
+  // ---- fly-fly collision (mj: mj_collision over the sphere / capsule pairs that survive MuJoCo's filters: same weld body,
+  //      parent-child, <exclude> (fruitfly.xml:733-760 + walk_on_ball.py:33-40), contype / conaffinity); condim 1, frictionless
+  //      (fruitfly.xml:17).  A link publishes up to two primitive geoms into LDS slots; lane s then owns slot s and tests it
+  //      against slots s + 1 .. s + NPG / 2 (mod NPG), so every unordered pair is visited once; sp_mask[s] bit j = (s, j) is a
+  //      candidate pair.  geom1 / geom2 in MuJoCo's order: the sphere first (lower type code), else the lower slot (checked).
+  int pg_slot[2][NL];
+  float pg_pos[2][3][NL], pg_axis[2][3][NL], pg_half[2][NL], pg_rad[2][NL];
+  int pgs_link[NPG];
+  float pgs_invw[NPG];
+  unsigned long long sp_mask[NL], sp_claw;  // candidate partners of each slot; slots whose geom carries the claw margin / gap
+  int npg, nsp, sp_sphere;                  // sp_sphere: slot of the one sphere (abdomen_7), or -1
+  float sc_margin, sc_gap, sc_K, sc_B, sc_solimp[5];  // margin / gap of a pair with a claw geom (others 0); K, B, solimp uniform (checked)
 };
 
 namespace detail {
@@ -528,6 +541,74 @@ inline BallHost build_ball_model(const Blob &b) {
     M.l_tree[l] = (unsigned)size | ((unsigned)(up(l, 2) + 1) << 8) | ((unsigned)(up(l, 4) + 1) << 16);
     M.l_pack[l] = (unsigned)(M.l_parent[l] + 1) | ((unsigned)M.l_depth[l] << 8) | ((unsigned)M.l_ndof[l] << 12);
     M.l_kids[l] = (unsigned)M.l_child[0][l] | ((unsigned)M.l_child[1][l] << 8) | ((unsigned)M.l_child[2][l] << 16) | ((unsigned)M.l_nchild[l] << 24);
+  }
+  // ---- fly-fly candidate pairs over the primitive geoms, filtered as mj_collision filters them
+  {
+    const Tensor &gct = b.get("geom_contype"), &gca = b.get("geom_conaffinity"), &excl = b.get("exclude_pairs"), &weld = b.get("body_weldid");
+    std::vector<int> slot_of((size_t)gbody.count, -1);
+    for (int l = 0; l < NL; l++) M.pg_slot[0][l] = M.pg_slot[1][l] = -1;
+    int npg = 0;
+    double sref[2] = {0, 0}, simp[5] = {0, 0, 0, 0, 0};
+    for (int g = 0; g < (int)gbody.count; g++) {
+      const int l = lane_of[gbody.i(g)], ty = gtype.i(g);
+      if (l < 0 || (ty != 2 && ty != 3)) continue;
+      if (npg >= NPG) throw std::runtime_error("ball model: more primitive geoms than slots");
+      const int w = M.pg_slot[0][l] < 0 ? 0 : 1;
+      if (M.pg_slot[w][l] >= 0) throw std::runtime_error("ball model: more than two primitive geoms on a link");
+      M.pg_slot[w][l] = npg; slot_of[g] = npg; M.pgs_link[npg] = l;
+      double q[4] = {gquat.f(4 * g), gquat.f(4 * g + 1), gquat.f(4 * g + 2), gquat.f(4 * g + 3)}, mm[9];
+      q2m(q, mm);
+      for (int k = 0; k < 3; k++) { M.pg_pos[w][k][l] = (float)gpos.f(3 * g + k); M.pg_axis[w][k][l] = ty == 3 ? (float)mm[3 * k + 2] : (k == 2 ? 1.f : 0.f); }
+      M.pg_rad[w][l] = (float)gsize.f(3 * g); M.pg_half[w][l] = ty == 3 ? (float)gsize.f(3 * g + 1) : 0.f;
+      M.pgs_invw[npg] = (float)binvw.f(2 * gbody.i(g));
+      if (gcondim.i(g) != 1) throw std::runtime_error("ball model: fly geoms are expected to be condim 1");
+      if (npg == 0) { for (int k = 0; k < 2; k++) sref[k] = gsolref.f(2 * g + k); for (int k = 0; k < 5; k++) simp[k] = gsolimp.f(5 * g + k); }
+      for (int k = 0; k < 2; k++) if (gsolref.f(2 * g + k) != sref[k]) throw std::runtime_error("ball model: fly geom solref is expected to be uniform");
+      for (int k = 0; k < 5; k++) if (gsolimp.f(5 * g + k) != simp[k]) throw std::runtime_error("ball model: fly geom solimp is expected to be uniform");
+      if (gmargin.f(g) != 0) {
+        if (M.sc_margin != 0 && (M.sc_margin != (float)gmargin.f(g) || M.sc_gap != (float)ggap.f(g))) throw std::runtime_error("ball model: one margin class expected");
+        M.sc_margin = (float)gmargin.f(g); M.sc_gap = (float)ggap.f(g);
+      }
+      npg++;
+    }
+    M.npg = npg;
+    double K, B;
+    kb(sref[0], sref[1], simp[1], h, &K, &B);  // mj_contactParam: equal solmix weights of equal parameters
+    M.sc_K = (float)K; M.sc_B = (float)B;
+    for (int k = 0; k < 5; k++) M.sc_solimp[k] = (float)simp[k];
+    M.sp_sphere = -1;
+    for (int g = 0; g < (int)gbody.count; g++) {
+      if (slot_of[g] < 0) continue;
+      if (gmargin.f(g) != 0) M.sp_claw |= 1ull << slot_of[g];
+      if (gtype.i(g) == 2) { if (M.sp_sphere >= 0) throw std::runtime_error("ball model: one sphere expected among the fly geoms"); M.sp_sphere = slot_of[g]; }
+    }
+    if (npg != NPG) throw std::runtime_error("ball model: the pair enumeration expects exactly NPG primitive geoms");
+    const int nex = (int)excl.count / 2;
+    for (int b1 = 0; b1 < nb; b1++) for (int b2 = b1 + 1; b2 < nb; b2++) {  // body-pair major order, as the oracle (and mj_collision) walk them
+      if (b1 == ball || b2 == ball) continue;
+      const int w1 = weld.i(b1), w2 = weld.i(b2);
+      if (w1 == w2) continue;
+      const int wp1 = weld.i(bpar.i(w1)), wp2 = weld.i(bpar.i(w2));
+      if (w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) continue;
+      bool skip = false;
+      for (int e = 0; e < nex; e++) skip |= (excl.i(2 * e) == b1 && excl.i(2 * e + 1) == b2) || (excl.i(2 * e) == b2 && excl.i(2 * e + 1) == b1);
+      if (skip) continue;
+      for (int ga = 0; ga < (int)gbody.count; ga++) {
+        if (gbody.i(ga) != b1 || slot_of[ga] < 0) continue;
+        for (int gb = 0; gb < (int)gbody.count; gb++) {
+          if (gbody.i(gb) != b2 || slot_of[gb] < 0) continue;
+          if (!((gct.i(ga) & gca.i(gb)) || (gct.i(gb) & gca.i(ga)))) continue;
+          int g1 = ga, g2 = gb;
+          if (gtype.i(g1) > gtype.i(g2)) std::swap(g1, g2);  // mj: lower type code first
+          const int s1 = slot_of[g1], s2 = slot_of[g2];
+          // the kernel derives the order instead of storing it
+          const int e1 = (s1 == M.sp_sphere || s2 == M.sp_sphere) ? M.sp_sphere : std::min(s1, s2);
+          if (e1 != s1) throw std::runtime_error("ball model: unexpected geom order of a fly-fly pair");
+          M.sp_mask[s1] |= 1ull << s2; M.sp_mask[s2] |= 1ull << s1;
+          M.nsp++;
+        }
+      }
+    }
   }
   (void)dbody; (void)djnt; (void)gcondim;
   return H;

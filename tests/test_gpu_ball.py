@@ -411,3 +411,158 @@ def test_reset_envs_restarts_a_subset_only(torch_mod):
     ints, _ = env.get_task_state()
     assert ints[:, 2].tolist() == [4, 0, 4, 4, 0, 4]
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------- fly-fly contacts
+def _fly_fly_states(n, seed=0, max_depth=0.003):
+    """Random joint poses (inside the joint ranges) in which the fly's own sphere / capsule geoms touch: legs against legs,
+    mouth parts against front legs, abdomen tip against hind tarsi, claws (margin + gap, adhesion).  Found with the oracle;
+    returns [(qpos, qvel, act, names of the touching pairs)] with shallow penetrations only."""
+    import json
+
+    from flybody_amd.model.blob import read_blob
+    from oracle import oracle as O
+
+    t = read_blob(BALL_BLOB)
+    meta = json.load(open(BALL_BLOB.replace(".ffmb", ".json")))
+    names, jname = meta["geom_name"], meta["jnt_name"]
+    m = O.OracleModel(BALL_BLOB)
+    d = O.OracleData(m)
+    rng = np.random.RandomState(seed)
+    hinge = [j for j in range(len(t["jnt_type"])) if t["jnt_type"][j] == 3]
+    cand = {"claw": [], "mouth": [], "other": []}
+    lo_, hi_ = t["jnt_range"][hinge].T
+    qa = t["jnt_qposadr"][hinge]
+
+    def pose(dq, amp):
+        q = t["qpos0"].copy()
+        q[qa] = np.clip(q[qa] + amp * dq * (hi_ - lo_) / 2, lo_, hi_)
+        d.qpos[:] = q; d.qvel[:] = 0; d.act[:] = 0; d.ctrl[:] = 0
+        d.forward()
+        c = d.contacts()
+        return q, c, [r for r in c if "ball" not in names[int(r[0])] and "ball" not in names[int(r[1])]]
+
+    for _ in range(2500):
+        if min(len(cand["claw"]), n // 4) + min(len(cand["mouth"]), n // 4) + len(cand["other"]) >= n + 8:
+            break
+        # a random direction in joint space, scaled up until the first fly-fly pair touches (bisection), then a little further:
+        # a shallow contact, as a simulation would meet it
+        dq = rng.uniform(-1, 1, len(hinge))
+        # move two legs plus (sometimes) the head / mouth parts and the abdomen; the other legs keep standing on the ball
+        moving = list(rng.choice(["T1_left", "T1_right", "T2_left", "T2_right", "T3_left", "T3_right"], 2, replace=False))
+        moving += [x for x in ("head", "rostrum", "haustellum", "labrum", "antenna") if rng.rand() < 0.5] + (["abdomen"] if rng.rand() < 0.5 else [])
+        dq *= np.array([any(k in jname[j] for k in moving) for j in hinge], dtype=float)
+        a0, a1 = 0.0, 1.0
+        if not pose(dq, a1)[2]:
+            continue
+        for _ in range(14):
+            am = 0.5 * (a0 + a1)
+            if pose(dq, am)[2]:
+                a1 = am
+            else:
+                a0 = am
+        q, c, sc = pose(dq, a1 + rng.uniform(0.002, 0.02))
+        if not sc or len(c) > 9 or d.nefc > 28 or any(r[5] < -max_depth for r in sc) or any(r[5] < -0.02 for r in c):
+            continue
+        legs = [names[int(r[1])].split("_collision")[0][-8:] for r in c if "ball" in names[int(r[0])]]
+        if any(legs.count(x) > 3 for x in legs):   # > 12 constraint rows in one block of M exceed the kernel's (flagged) capacity
+            continue
+        pairs = [(names[int(r[0])], names[int(r[1])]) for r in sc]
+        kind = "claw" if any("claw" in x or "claw" in y for x, y in pairs) else (
+            "mouth" if any(x.split("_")[0] in ("rostrum", "haustellum", "antenna") for x, y in pairs) else "other")
+        cand[kind].append((q.copy(), rng.randn(m.nv) * 2.0, rng.uniform(-0.3, 0.3, m.na), pairs))
+    out = cand["claw"][: n // 4] + cand["mouth"][: n // 4]   # the rarer kinds first, the rest legs against legs / abdomen tip
+    out += cand["other"][: n - len(out)]
+    assert len(out) == n
+    return m, names, out
+
+
+@pytest.mark.parametrize("flags,name", [(128 | 256, "contacts"), (0, "full")])
+def test_fly_fly_contacts_one_substep(torch_mod, flags, name):
+    """a17: the fly's own sphere / capsule pairs (condim 1, fruitfly.xml:16-25; excludes fruitfly.xml:733-760 +
+    walk_on_ball.py:33-40) collide on the GPU as in the oracle.  States with legs crossing, mouth parts on the front legs,
+    the abdomen tip on the hind tarsi and claws (margin / gap / adhesion sharing) are put into both through set_state; after
+    one physics substep the contact counts agree and qvel matches at the tolerance of test_one_substep_teacher_forced."""
+    from oracle import oracle as O
+
+    m, names, states = _fly_fly_states(32, seed=3)
+    rs = np.random.RandomState(5)
+    ctrls = [rs.uniform(-0.5, 0.5, 59).astype(np.float32) for _ in states]
+    ref, nself = [], []
+    d = O.OracleData(m)
+    for s_, c_ in zip(states, ctrls):
+        m.set_flags(flags)
+        d.qpos[:], d.qvel[:], d.act[:] = s_[:3]
+        d.ctrl[:] = c_
+        d.step1()
+        con = d.contacts()
+        nself.append((len(con), sum(1 for r in con if "ball" not in names[int(r[0])] and "ball" not in names[int(r[1])])))
+        d.step2()
+        d.step1()
+        ref.append((d.qpos.copy(), d.qvel.copy(), d.act.copy()))
+        m.set_flags(0)
+    # GPU: the contact set used by the substep is the one of the initial position stage, so count it with 0 substeps first
+    q, v, a, ints = _gpu_advance(torch_mod, [s_[:3] for s_ in states], ctrls, 1, flags)
+    eq, ev, ea = _report("fly-fly " + name, q, v, a, ref)
+    kinds = sorted({(x.rsplit("_collision", 1)[0].split("_")[0], y.rsplit("_collision", 1)[0].split("_")[0]) for s_ in states for x, y in s_[3]})
+    print("pair kinds covered:", kinds, " self-contact counts (oracle)", [n for _, n in nself], "overflow", ints[:, 7].tolist())
+    assert max(n for _, n in nself) >= 2 and any("claw" in x or "claw" in y for s_ in states for x, y in s_[3])
+    assert (ints[:, 7] == 0).all()
+    assert ea < 1e-6 and eq < 2e-6, name
+    assert ev < 1.5e-4, name
+
+
+def test_fly_fly_contact_counts_and_sensors(torch_mod):
+    """Same states through the task layer: one control step (10 substeps, sensors, reward) teacher-forced from each state.
+    The number of contacts the GPU found at the state (ffe_get_task_state) equals the oracle's, and where the per-substep
+    contact history agrees, the touch / force sensors, joint velocities and the reward match at the tolerances of
+    test_env_protocol_and_observation_parity."""
+    from flybody_amd import fly_envs
+    from oracle import oracle as O
+
+    torch = torch_mod
+    m, names, states = _fly_fly_states(16, seed=7, max_depth=0.0015)
+    B = len(states)
+    env = fly_envs.walk_on_ball(batch_size=B)
+    env.reset()
+    env.set_state(torch.tensor(np.stack([s_[0] for s_ in states])), torch.tensor(np.stack([s_[1] for s_ in states])))
+    env.set_act(torch.tensor(np.stack([s_[2] for s_ in states])))
+    # contacts at the state itself: a zero-length physics step is not available, so read them after the control step's
+    # first stage through the history instead (column 0-1), and the totals of the final state through columns 3 and 5
+    rs = np.random.RandomState(2)
+    a = rs.uniform(-0.2, 0.2, (B, 59)).astype(np.float32)
+    ts = env.step(torch.tensor(a, device="cuda"))
+    obs = env.flat_observation.cpu().numpy()
+    rew = ts.reward.cpu().numpy()
+    ghist = _gpu_contact_history(env)
+    ints, _ = env.get_task_state()
+    ints = ints.cpu().numpy()
+    groups = _obs_groups()
+    oenv = O.OracleBallEnv(m)
+    oenv.reset()
+    n_ok, n_flip = 0, 0
+    worst = {k: 0.0 for k in groups}
+    worst_r = 0.0
+    for i, s_ in enumerate(states):
+        d = oenv.data
+        d.qpos[:], d.qvel[:], d.act[:] = s_[:3]
+        d.step1()
+        st, r, dsc, o = oenv.step(a[i].astype(np.float64))
+        ohist, ogap = oenv.contact_history()
+        assert ohist[0] == ghist[i, 0], (i, ohist, ghist[i])      # the contact set of the given state itself
+        if (ohist != ghist[i]).any():
+            n_flip += 1
+            assert ogap.min() < 2e-6
+            continue
+        n_ok += 1
+        c = d.contacts()
+        assert len(c) == ints[i, 5] and sum(1 for row in c if "ball" not in names[int(row[0])] and "ball" not in names[int(row[1])]) == ints[i, 3]
+        worst_r = max(worst_r, abs(r - rew[i]))
+        for name, (lo, hi) in groups.items():
+            worst[name] = max(worst[name], np.abs(obs[i, lo:hi] - o[lo:hi]).max() / max(1.0, np.abs(o[lo:hi]).max()))
+    print(f"fly-fly states, one control step: {n_ok} compared, {n_flip} contact flips; reward {worst_r:.2e}", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert n_ok >= B // 2
+    assert worst_r < TOL["reward"]
+    for name in groups:
+        assert worst[name] < 3 * TOL[name], (name, worst[name])
+    env.close()
