@@ -525,6 +525,51 @@ __device__ __noinline__ void self_rows(BTile *Tp, ModelPtr Mp, const int lane, c
   DM_SYNC();
 }
 
+// J' of the fly-fly rows into the right-hand sides of a block solve: over geom1's chain, then (the chains may share dofs)
+// accumulated over geom2's chain.  X4 has been zeroed and filled by the other rows; columns as assigned in stage 2.
+__device__ __noinline__ void self_rhs(BTile *Tp, const int lane, const int nc, const int nsc, const int nrc, const int cb) {
+  BTile &T = *Tp;
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    DM_SYNC();
+    for (int item = lane; item < nsc * 16; item += 64) {
+      const int j = item >> 4, p = item & 15, k = nc + j;
+      const int nch = (T.c_nch[k] >> (8 * half)) & 0xff;
+      const int col = (half == 0 ? (int)T.r_col[nrc + j] : (int)sc_chain_b(T, k)[14]) + 1 - cb;
+      if (p < nch && col >= 0 && col < 4) {
+        const int f = half == 0 ? (int)T.c_chain[k][p] : (int)sc_chain_b(T, k)[p];
+        (&T.X4[f].x)[col] += T.c_J[k][half][p];
+      }
+    }
+  }
+}
+// rows of G owned by fly-fly contacts: J over each of the two chains against the solved columns of that chain's block
+__device__ __noinline__ void self_gacc(BTile *Tp, const int lane, const int nc, const int nsc, const int nrc, const int cb) {
+  BTile &T = *Tp;
+  if (lane < nrc || lane >= nrc + nsc) return;
+  const int k = nc + lane - nrc, gtri = lane * (lane + 1) / 2;
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    const int nch = (T.c_nch[k] >> (8 * half)) & 0xff, b = (T.c_blk[k] >> (8 * half)) & 0xff;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < nch; p++) {
+      const float jv = T.c_J[k][half][p];
+      const float4 y = T.X4[half == 0 ? (int)T.c_chain[k][p] : (int)sc_chain_b(T, k)[p]];
+      acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < 4; q2++) {
+      const int gc = cb + q2;
+      const float av = q2 == 0 ? acc.x : (q2 == 1 ? acc.y : (q2 == 2 ? acc.z : acc.w));
+      if (gc == 0) T.r_y0[lane] += av;  // J a_s
+      else if (gc - 1 < 12) {
+        const int r2 = T.rowof[b][gc - 1];
+        if (r2 <= lane) T.G[gtri + r2] += av;  // (255 = no such row)
+      }
+    }
+  }
+}
+
 // sum over the fly-fly contacts whose row touches fly dof (blk, li) of J[c][p] * w[c][0]
 __device__ __forceinline__ float self_gather(const Ctx &c, unsigned sbl, const float (*w)[3]) {
   const BTile &T = *c.T;
@@ -745,6 +790,11 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     const V3 gp = c.xp + mv(xmat, V3{M.g_pos[0][lane], M.g_pos[1][lane], M.g_pos[2][lane]});
     const V3 ax = mv(xmat, V3{M.g_axis[0][lane], M.g_axis[1][lane], M.g_axis[2][lane]});
     const float half = M.g_half[lane], rad = M.g_rad[lane], x = fminf(fmaxf(dot(ax, bc - gp), -half), half);
+    {  // publish the geom for the fly-fly pair tests below (the link-exchange area is free between the factorisation and stage 2)
+      float *o = reinterpret_cast<float(*)[8]>(&T.lk[0][0])[M.g_slot[lane]];
+      *reinterpret_cast<float4 *>(o) = make_float4(gp.x, gp.y, gp.z, ax.x);
+      *reinterpret_cast<float4 *>(o + 4) = make_float4(ax.y, ax.z, half, rad);
+    }
     margin = M.g_margin[lane]; gap = M.g_gap[lane];
     const V3 dif = gp + x * ax - bc;
     const float cd = fsqrt(dot(dif, dif));
@@ -790,19 +840,19 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   //      stage 2; the pair tests read them back from there.
   c.nsc = 0;
   if (!(c.flags & BF_NO_CONTACT)) {
-    float(*pg)[8] = reinterpret_cast<float(*)[8]>(&T.lk[0][0]);
-#pragma unroll
-    for (int w = 0; w < 2; w++) {
-      const int slot = M.pg_slot[w][lane];
-      if (slot >= 0) {
-        const V3 gc = c.xp + mv(xmat, V3{M.pg_pos[w][0][lane], M.pg_pos[w][1][lane], M.pg_pos[w][2][lane]});
-        const V3 ga = mv(xmat, V3{M.pg_axis[w][0][lane], M.pg_axis[w][1][lane], M.pg_axis[w][2][lane]});
-        float *o = pg[slot];
-        o[0] = gc.x; o[1] = gc.y; o[2] = gc.z; o[3] = ga.x; o[4] = ga.y; o[5] = ga.z; o[6] = M.pg_half[w][lane]; o[7] = M.pg_rad[w][lane];
-      }
+    if (lane == M.pg2_lane) {  // the rostrum's second capsule
+      const V3 gc = c.xp + mv(xmat, V3{M.pg2_pos[0], M.pg2_pos[1], M.pg2_pos[2]});
+      const V3 ga = mv(xmat, V3{M.pg2_axis[0], M.pg2_axis[1], M.pg2_axis[2]});
+      float *o = reinterpret_cast<float(*)[8]>(&T.lk[0][0])[M.pg2_slot];
+      *reinterpret_cast<float4 *>(o) = make_float4(gc.x, gc.y, gc.z, ga.x);
+      *reinterpret_cast<float4 *>(o + 4) = make_float4(ga.y, ga.z, M.pg2_half, M.pg2_rad);
     }
     DM_SYNC();
-    const int sc = self_collide(c.T, (ModelPtr)c.M, lane, c.nc);
+#ifdef FFB_SC_NOCALL
+    const int sc = 0;
+#else
+    const int sc = __builtin_amdgcn_readfirstlane(self_collide(c.T, (ModelPtr)c.M, lane, c.nc));  // wave-uniform by construction
+#endif
     c.nsc = sc & 0xff;
     if (sc >> 8) c.overflow = 1;
     for (int k = c.nc; k < c.nc + c.nsc; k++) c.nact += T.c_excl[k] ? 0 : 1;
@@ -1193,7 +1243,11 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
   }
   DM_SYNC();
+#ifdef FFB_SC_NOSTAGE2
+  const int nsc = 0;
+#else
   const int nsc = c.nsc;
+#endif
   if (nsc) self_rows(c.T, (ModelPtr)c.M, lane, nc, nsc);  // fly-fly contacts (rare): rows, impedance, adhesion shares
   BSTAMP(6);  // actuation + contact rows
   // ---- smooth forces (mj: mj_fwdAcceleration); the smooth acceleration a_s = M^-1 qfrc_smooth rides as column 0 of the
@@ -1342,21 +1396,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       const int col = (int)T.r_col[lane] + 1 - cb;
       if (col >= 0 && col < 4) (&T.X4[T.r_dof[lane]].x)[col] = T.r_sgn[lane];
     }
-    if (nsc) {  // fly-fly rows: J' over geom1's chain, then (the chains may share dofs) accumulated over geom2's chain
-#pragma unroll 1
-      for (int half = 0; half < 2; half++) {
-        DM_SYNC();
-        for (int item = lane; item < nsc * 16; item += 64) {
-          const int j = item >> 4, p = item & 15, k = nc + j;
-          const int nch = (T.c_nch[k] >> (8 * half)) & 0xff;
-          const int col = (half == 0 ? (int)T.r_col[nrc + j] : (int)sc_chain_b(T, k)[14]) + 1 - cb;
-          if (p < nch && col >= 0 && col < 4) {
-            const int f = half == 0 ? (int)T.c_chain[k][p] : (int)sc_chain_b(T, k)[p];
-            (&T.X4[f].x)[col] += T.c_J[k][half][p];
-          }
-        }
-      }
-    }
+    if (nsc) self_rhs(c.T, lane, nc, nsc, nrc, cb);
     DM_SYNC();
     solve4(c, T.Lm, T.dinv_m);
     if (cb == 0) {
@@ -1372,13 +1412,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           const float4 y = T.X4[T.c_chain[k][p]];
           acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
         }
-      } else if (lane < nrc + nsc) {  // fly-fly row: geom1's chain here, geom2's chain below
-        const int k = nc + lane - nrc, nch = T.c_nch[k] & 0xff;
-        for (int p = 0; p < nch; p++) {
-          const float jv = T.c_J[k][0][p];
-          const float4 y = T.X4[T.c_chain[k][p]];
-          acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
-        }
+      } else if (lane < nrc + nsc) {  // fly-fly row: self_gacc below
       } else {
         const float sg = T.r_sgn[lane];
         const float4 y = T.X4[T.r_dof[lane]];
@@ -1395,26 +1429,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
           if (r2 <= lane) T.G[gtri + r2] += av;  // (255 = no such row)
         }
       }
-      if (nsc && lane >= nrc && lane < nrc + nsc) {  // second chain of a fly-fly row, against the columns of its own block
-        const int k = nc + lane - nrc, nch = (T.c_nch[k] >> 8) & 0xff, b2 = T.c_blk[k] >> 8;
-        float4 ac2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = 0; p < nch; p++) {
-          const float jv = T.c_J[k][1][p];
-          const float4 y = T.X4[sc_chain_b(T, k)[p]];
-          ac2.x += jv * y.x; ac2.y += jv * y.y; ac2.z += jv * y.z; ac2.w += jv * y.w;
-        }
-#pragma unroll
-        for (int q2 = 0; q2 < 4; q2++) {
-          const int gc = cb + q2;
-          const float av = q2 == 0 ? ac2.x : (q2 == 1 ? ac2.y : (q2 == 2 ? ac2.z : ac2.w));
-          if (gc == 0) T.r_y0[lane] += av;
-          else if (gc - 1 < 12) {
-            const int r2 = T.rowof[b2][gc - 1];
-            if (r2 <= lane) T.G[gtri + r2] += av;
-          }
-        }
-      }
     }
+    if (nsc) self_gacc(c.T, lane, nc, nsc, nrc, cb);
     DM_SYNC();
   }
   BSTAMP(8);  // constraint rows + G

@@ -110,8 +110,9 @@ struct BallModel {
   //      (fruitfly.xml:17).  A link publishes up to two primitive geoms into LDS slots; lane s then owns slot s and tests it
   //      against slots s + 1 .. s + NPG / 2 (mod NPG), so every unordered pair is visited once; sp_mask[s] bit j = (s, j) is a
   //      candidate pair.  geom1 / geom2 in MuJoCo's order: the sphere first (lower type code), else the lower slot (checked).
-  int pg_slot[2][NL];
-  float pg_pos[2][3][NL], pg_axis[2][3][NL], pg_half[2][NL], pg_rad[2][NL];
+  int g_slot[NL];                              // slot of the link's (first) primitive geom = the g_* capsule above, or -1
+  int pg2_lane, pg2_slot;                      // the one link with a second primitive geom (rostrum: left + right capsule)
+  float pg2_pos[3], pg2_axis[3], pg2_half, pg2_rad;
   int pgs_link[NPG];
   float pgs_invw[NPG];
   unsigned long long sp_mask[NL], sp_claw;  // candidate partners of each slot; slots whose geom carries the claw margin / gap
@@ -437,7 +438,7 @@ inline BallHost build_ball_model(const Blob &b) {
     if (l < 0) continue;
     int ty = gtype.i(g);
     if (ty != 2 && ty != 3) continue;  // ellipsoids / cylinders cannot reach the ball
-    if (M.g_has[l]) { M.g_has[l] = 2; continue; }  // several capsules on one link (mouth parts): none can reach the ball
+    if (M.g_has[l]) continue;  // a second capsule on the link (rostrum): fly-fly collision only, it cannot reach the ball
     M.g_has[l] = 1;
     double q[4] = {gquat.f(4 * g), gquat.f(4 * g + 1), gquat.f(4 * g + 2), gquat.f(4 * g + 3)}, mm[9];
     q2m(q, mm);
@@ -456,7 +457,6 @@ inline BallHost build_ball_model(const Blob &b) {
     for (int k = 0; k < 5; k++) M.g_solimp[k][l] = (float)si[k];
     M.g_invw[l] = (float)(binvw.f(2 * gbody.i(g)) + binvw.f(2 * ball));
   }
-  for (int l = 0; l < NL; l++) if (M.g_has[l] == 2) M.g_has[l] = 0;
   const Tensor &sbody = b.get("sites_bodyid"), &squat = b.get("sites_quat"), &spos = b.get("sites_pos"), &tsite = b.get("touch_site"),
                &fsite = b.get("force_site"), &asite = b.get("appendage_site");
   for (int t = 0; t < (int)tsite.count; t++) M.l_touch[lane_of[sbody.i(tsite.i(t))]] = t;
@@ -546,20 +546,26 @@ inline BallHost build_ball_model(const Blob &b) {
   {
     const Tensor &gct = b.get("geom_contype"), &gca = b.get("geom_conaffinity"), &excl = b.get("exclude_pairs"), &weld = b.get("body_weldid");
     std::vector<int> slot_of((size_t)gbody.count, -1);
-    for (int l = 0; l < NL; l++) M.pg_slot[0][l] = M.pg_slot[1][l] = -1;
+    for (int l = 0; l < NL; l++) M.g_slot[l] = -1;
+    M.pg2_lane = M.pg2_slot = -1;
     int npg = 0;
     double sref[2] = {0, 0}, simp[5] = {0, 0, 0, 0, 0};
     for (int g = 0; g < (int)gbody.count; g++) {
       const int l = lane_of[gbody.i(g)], ty = gtype.i(g);
       if (l < 0 || (ty != 2 && ty != 3)) continue;
       if (npg >= NPG) throw std::runtime_error("ball model: more primitive geoms than slots");
-      const int w = M.pg_slot[0][l] < 0 ? 0 : 1;
-      if (M.pg_slot[w][l] >= 0) throw std::runtime_error("ball model: more than two primitive geoms on a link");
-      M.pg_slot[w][l] = npg; slot_of[g] = npg; M.pgs_link[npg] = l;
+      slot_of[g] = npg; M.pgs_link[npg] = l;
       double q[4] = {gquat.f(4 * g), gquat.f(4 * g + 1), gquat.f(4 * g + 2), gquat.f(4 * g + 3)}, mm[9];
       q2m(q, mm);
-      for (int k = 0; k < 3; k++) { M.pg_pos[w][k][l] = (float)gpos.f(3 * g + k); M.pg_axis[w][k][l] = ty == 3 ? (float)mm[3 * k + 2] : (k == 2 ? 1.f : 0.f); }
-      M.pg_rad[w][l] = (float)gsize.f(3 * g); M.pg_half[w][l] = ty == 3 ? (float)gsize.f(3 * g + 1) : 0.f;
+      if (M.g_slot[l] < 0) {  // the link's first primitive geom is the g_* capsule filled above (same geom order)
+        M.g_slot[l] = npg;
+        if (!M.g_has[l] || M.g_rad[l] != (float)gsize.f(3 * g) || M.g_pos[0][l] != (float)gpos.f(3 * g)) throw std::runtime_error("ball model: geom tables out of step");
+      } else {
+        if (M.pg2_lane >= 0) throw std::runtime_error("ball model: one link with two primitive geoms expected");
+        M.pg2_lane = l; M.pg2_slot = npg;
+        for (int k = 0; k < 3; k++) { M.pg2_pos[k] = (float)gpos.f(3 * g + k); M.pg2_axis[k] = ty == 3 ? (float)mm[3 * k + 2] : (k == 2 ? 1.f : 0.f); }
+        M.pg2_rad = (float)gsize.f(3 * g); M.pg2_half = ty == 3 ? (float)gsize.f(3 * g + 1) : 0.f;
+      }
       M.pgs_invw[npg] = (float)binvw.f(2 * gbody.i(g));
       if (gcondim.i(g) != 1) throw std::runtime_error("ball model: fly geoms are expected to be condim 1");
       if (npg == 0) { for (int k = 0; k < 2; k++) sref[k] = gsolref.f(2 * g + k); for (int k = 0; k < 5; k++) simp[k] = gsolimp.f(5 * g + k); }
