@@ -8,14 +8,99 @@ are accumulated with the same keys the reference logs (`episode_length`, `episod
 
 from __future__ import annotations
 
+import ctypes as C
 import time
+
+from . import _capi
+
+
+class NStepTransitionWriter:
+    """Device-resident batched n-step transition adder (`ffe_nstep_*`, flybody_amd/csrc/nstep.hip): what the reference's
+    actors do one env at a time through `acme.adders.reverb.NStepTransitionAdder(n_step=50, discount=...)`
+    (`agents/ray_distributed_dmpo.py:514-521`, `agents/actors.py:91-101`), for B envs per call, into a replay ring in HBM.
+
+    `observe(action, timestep)` takes the action that was applied and the `TimeStep` the env returned for it (FIRST rows start
+    an episode; their action is ignored).  `transitions()` returns views (obs, action, n_step_return, discount, next_obs) of the
+    slots written so far; the learner applies one more factor of `discount` to the bootstrap value, as with acme."""
+
+    def __init__(self, batch_size: int, obs_dim: int, act_dim: int, *, n_step: int = 50, discount: float = 0.99, capacity: int = 1 << 20,
+                 device: int = 0):
+        import torch
+
+        self._t, self._L = torch, _capi.lib()
+        self.batch_size, self.obs_dim, self.act_dim, self.n_step, self.discount, self.capacity = batch_size, obs_dim, act_dim, n_step, discount, capacity
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        if self._L.ffe_nstep_create(batch_size, obs_dim, act_dim, n_step, float(discount), capacity, device, C.byref(h)) != 0:
+            raise RuntimeError("ffe_nstep_create: " + self._L.ffe_nstep_last_error(None).decode())
+        self._h = h
+        ptr = [C.c_void_p() for _ in range(6)]
+        assert self._L.ffe_nstep_buffers(self._h, *[C.byref(p) for p in ptr]) == 0
+        self._ptr = [p.value for p in ptr]
+
+    def observe(self, action, timestep, flat_observation):
+        t = self._t
+        st = timestep.step_type
+        assert action.is_cuda and action.dtype == t.float32 and action.is_contiguous() and tuple(action.shape) == (self.batch_size, self.act_dim)
+        assert flat_observation.is_contiguous() and tuple(flat_observation.shape) == (self.batch_size, self.obs_dim)
+        stream = C.c_void_p(t.cuda.current_stream(self.device).cuda_stream)
+        rc = self._L.ffe_nstep_observe(self._h, action.data_ptr(), st.data_ptr(), timestep.reward.data_ptr(), timestep.discount.data_ptr(),
+                                       flat_observation.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError("ffe_nstep_observe: " + self._L.ffe_nstep_last_error(self._h).decode())
+
+    def num_written(self) -> int:
+        """Transitions written since creation (synchronises)."""
+        import numpy as np
+
+        t = self._t
+        t.cuda.synchronize(self.device)
+        out = np.zeros(1, dtype=np.uint64)
+        # 8 bytes device -> host through a torch view of the counter
+        cnt = self._view(self._ptr[5], (1,), t.int64)
+        return int(cnt.cpu()[0])
+
+    def _view(self, ptr, shape, dtype):
+        """torch tensor over library-owned device memory (no copy), via the CUDA array interface."""
+        t = self._t
+        itemsize = {t.float32: 4, t.int64: 8}[dtype]
+        typestr = {t.float32: "<f4", t.int64: "<i8"}[dtype]
+
+        class _Mem:
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+
+        del itemsize
+        return t.as_tensor(_Mem(), device=self.device)
+
+    def transitions(self):
+        """(obs [N,O], action [N,A], n_step_return [N], discount [N], next_obs [N,O]) views of the N = min(written, capacity) filled slots."""
+        t, n = self._t, min(self.num_written(), self.capacity)
+        o = self._view(self._ptr[0], (self.capacity, self.obs_dim), t.float32)[:n]
+        a = self._view(self._ptr[1], (self.capacity, self.act_dim), t.float32)[:n]
+        r = self._view(self._ptr[2], (self.capacity,), t.float32)[:n]
+        d = self._view(self._ptr[3], (self.capacity,), t.float32)[:n]
+        o2 = self._view(self._ptr[4], (self.capacity, self.obs_dim), t.float32)[:n]
+        return o, a, r, d, o2
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ffe_nstep_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BatchedActorLoop:
-    def __init__(self, env, policy):
+    def __init__(self, env, policy, adder: NStepTransitionWriter | None = None):
+        """`adder`: optional `NStepTransitionWriter`; fed as the reference's actor feeds its adder (`observe_first` on FIRST,
+        `observe(action, next_timestep)` otherwise)."""
         import torch
 
-        self._t, self.env, self.policy = torch, env, policy
+        self._t, self.env, self.policy, self.adder = torch, env, policy, adder
         B, dev = env.batch_size, env.device
         self._ret = torch.zeros(B, device=dev)
         self._len = torch.zeros(B, dtype=torch.int64, device=dev)
@@ -30,11 +115,16 @@ class BatchedActorLoop:
         t = self._t
         ts = self.env.reset()
         self._ret.zero_(); self._len.zero_()
+        if self.adder is not None:
+            self.adder.observe(t.zeros(self.env.batch_size, self.adder.act_dim, device=self.env.device), ts, self.env.flat_observation)
         start = time.perf_counter()
         for _ in range(num_steps):
             with t.no_grad():
                 action = self.policy(self.env.flat_observation)
-            ts = self.env.step(action.contiguous())
+            action = action.contiguous()
+            ts = self.env.step(action)
+            if self.adder is not None:
+                self.adder.observe(action, ts, self.env.flat_observation)
             mid_or_last = ts.step_type != 0
             self._ret += t.where(mid_or_last, ts.reward, t.zeros_like(ts.reward))
             self._len += mid_or_last.to(t.int64)

@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libflybody_env.so")
-SOURCES = ["fly_env.hip", "ball_env.hip"]
+SOURCES = ["fly_env.hip", "ball_env.hip", "nstep.hip"]
 HEADERS = ["dev_model.hpp", "ball_model.hpp", "ball_env.hpp", "dev_math.hpp", "launch_order.hpp", os.path.join("..", "..", "include", "flybody_env.h")]
 
 

@@ -164,6 +164,24 @@ int ffe_test_quat(int op, const float *a_dev, const float *b_dev, float *out_dev
 const char *ffe_last_error(ffe_handle h);
 const char *ffe_version(void);
 
+/* ---- bulk n-step transition writer: the adder the reference's actors feed, batched and device-resident.
+ * Replaces acme.adders.reverb.NStepTransitionAdder(n_step, discount) as built at agents/ray_distributed_dmpo.py:514-521
+ * (n_step = 50, train_dmpo_ray.py:236) and driven through actor.observe_first / actor.observe (agents/actors.py:91-101).
+ * One call per env step with the action that was applied and the timestep ffe_step returned; FIRST rows start an episode
+ * (their action is ignored).  Per env, once n entries are held each call writes (o_t-n+1, a_t-n+1, R, D, o_t+1) with
+ * R = r_0 + g d_0 r_1 + g^2 d_0 d_1 r_2 + ... and D = g^(n-1) d_0 ... d_(n-1); LAST also flushes the shorter tails.
+ * Transitions go to a device replay ring of `capacity` slots (slot = count mod capacity).  acme is not in the reference tree:
+ * these semantics restate its published behaviour (parity unpinned, tests/test_nstep.py). */
+typedef struct ffe_nstep *ffe_nstep_handle;
+int ffe_nstep_create(int batch, int obs_dim, int act_dim, int n_step, float discount, long long capacity, int device, ffe_nstep_handle *out);
+int ffe_nstep_observe(ffe_nstep_handle h, const float *action_dev, const int32_t *step_type_dev, const float *reward_dev,
+                      const float *discount_dev, const float *obs_dev, void *stream);
+/* device pointers of the replay ring: obs[capacity][O], act[capacity][A], n-step return[capacity], discount[capacity],
+ * next_obs[capacity][O], and the running count of transitions written */
+int ffe_nstep_buffers(ffe_nstep_handle h, float **obs, float **act, float **ret, float **disc, float **next_obs, unsigned long long **written_dev);
+int ffe_nstep_destroy(ffe_nstep_handle h);
+const char *ffe_nstep_last_error(ffe_nstep_handle h);
+
 #ifdef __cplusplus
 }
 #endif
