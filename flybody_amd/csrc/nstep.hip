@@ -45,6 +45,7 @@ __device__ __forceinline__ void emit(const Dev &D, int env, int lane, int first,
   // float32 result matches a scalar restatement bit for bit
   float ret = 0.f, td = 1.f;
   if (lane == 0) {
+#pragma clang fp contract(off)
     for (int i = s; i < len; i++) {
       const int e = (first + i) % n;
       if (i == s) { ret = rr[e]; td = rd[e]; }
@@ -100,6 +101,15 @@ __global__ __launch_bounds__(64) void nstep_observe_kernel(Dev D, const float *_
   }
   for (int k = lane; k < O; k += 64) lo[k] = o_next[k];
   if (lane == 0) { D.head[env] = head; D.count[env] = cnt; }
+}
+
+// one [B][O + 3] row per env: observation | reward | discount | step_type (as float): the unit the per-step gather moves
+__global__ void pack_timestep_kernel(const float *__restrict__ obs, const float *__restrict__ rew, const float *__restrict__ disc,
+                                     const int *__restrict__ st, float *__restrict__ out, int batch, int obs_dim) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, w = obs_dim + 3;
+  if (i >= (long long)batch * w) return;
+  const int env = (int)(i / w), k = (int)(i - (long long)env * w);
+  out[i] = k < obs_dim ? obs[(long long)env * obs_dim + k] : (k == obs_dim ? rew[env] : (k == obs_dim + 1 ? disc[env] : (float)st[env]));
 }
 
 struct Handle {
@@ -197,5 +207,14 @@ int ffe_nstep_buffers(ffe_nstep_handle p, float **obs, float **act, float **ret,
 }
 
 const char *ffe_nstep_last_error(ffe_nstep_handle p) { return p ? p->h.err.c_str() : g_nerr.c_str(); }
+
+int ffe_pack_timestep(const float *obs_dev, const float *reward_dev, const float *discount_dev, const int32_t *step_type_dev, float *packed_dev,
+                      int batch, int obs_dim, void *stream) {
+  if (!obs_dev || !reward_dev || !discount_dev || !step_type_dev || !packed_dev || batch <= 0 || obs_dim <= 0) return -1;
+  const long long total = (long long)batch * (obs_dim + 3);
+  hipLaunchKernelGGL(ffn::pack_timestep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), obs_dev, reward_dev,
+                     discount_dev, step_type_dev, packed_dev, batch, obs_dim);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 }  // extern "C"

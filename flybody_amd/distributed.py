@@ -31,10 +31,19 @@ class TimestepGather:
         must be waited on before this object is used again (double-buffer two of them to overlap the gather of step k
         with the physics of step k+1)."""
         p = self.pack
-        p[:, : self.obs_dim] = obs
-        p[:, -3] = reward
-        p[:, -2] = discount
-        p[:, -1] = step_type.to(torch.float32)
+        if p.is_cuda and obs.is_contiguous() and obs.dtype == torch.float32:  # one fused launch (ffe_pack_timestep) instead of four
+            from . import _capi
+
+            with torch.cuda.device(p.device):
+                rc = _capi.lib().ffe_pack_timestep(obs.data_ptr(), reward.data_ptr(), discount.data_ptr(), step_type.data_ptr(), p.data_ptr(),
+                                                   p.shape[0], self.obs_dim, torch.cuda.current_stream(p.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError("ffe_pack_timestep failed")
+        else:
+            p[:, : self.obs_dim] = obs
+            p[:, -3] = reward
+            p[:, -2] = discount
+            p[:, -1] = step_type.to(torch.float32)
         if self.world > 1:
             work = dist.gather(p, self.out, dst=0, async_op=async_op)
             if async_op:

@@ -180,6 +180,11 @@ int ffe_nstep_observe(ffe_nstep_handle h, const float *action_dev, const int32_t
  * next_obs[capacity][O], and the running count of transitions written */
 int ffe_nstep_buffers(ffe_nstep_handle h, float **obs, float **act, float **ret, float **disc, float **next_obs, unsigned long long **written_dev);
 int ffe_nstep_destroy(ffe_nstep_handle h);
+/* The unit the per-step gather to a central learner moves (the reference has no collective - its actors
+ * push transitions through Reverb, agents/ray_distributed_dmpo.py:106-115): one fused launch packs (obs, reward, discount,
+ * step_type) of the current device into packed_dev[B][obs_dim + 3] (flybody_amd/distributed.py:TimestepGather). */
+int ffe_pack_timestep(const float *obs_dev, const float *reward_dev, const float *discount_dev, const int32_t *step_type_dev,
+                      float *packed_dev, int batch, int obs_dim, void *stream);
 const char *ffe_nstep_last_error(ffe_nstep_handle h);
 
 #ifdef __cplusplus

@@ -98,3 +98,23 @@ def test_actor_loop_feeds_the_writer(torch_mod=None):
     assert stats["episodes"] > 0 and n > B * 100 and torch.isfinite(r).all() and (d >= 0).all() and (d <= 1).all()
     assert float(r.max()) <= 50.0 and float(r.min()) >= 0.0   # 50 rewards in [0, 1]
     w.close(); env.close()
+
+
+def test_fused_timestep_pack_matches_torch():
+    """flybody_amd.distributed.TimestepGather's fused pack (ffe_pack_timestep) == the four torch slice assignments."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flybody_amd.distributed import TimestepGather
+
+    B, O = 1000, 104
+    g = torch.Generator(device="cuda").manual_seed(0)
+    obs = torch.rand(B, O, device="cuda", generator=g)
+    rew, disc = torch.rand(B, device="cuda", generator=g), (torch.rand(B, device="cuda", generator=g) > 0.1).float()
+    st = torch.randint(0, 3, (B,), device="cuda", generator=g, dtype=torch.int32)
+    tg = TimestepGather(B, O, torch.device("cuda", 0), world=1, rank=0)
+    tg(obs, rew, disc, st)
+    torch.cuda.synchronize()
+    uo, ur, ud, us = TimestepGather.unpack(tg.pack, O)
+    assert torch.equal(uo, obs) and torch.equal(ur, rew) and torch.equal(ud, disc) and torch.equal(us, st)
