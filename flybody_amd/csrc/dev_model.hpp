@@ -90,6 +90,11 @@ struct DevModel {
   // per dof
   const int FFE_GLOBAL *d_link, *d_madr, *d_depth, *d_kind, *d_qadr, *d_limited, *d_act_id, *d_ndesc;  // d_act_id: [2][64]
   const unsigned int FFE_GLOBAL *pairtab;  // [256] elimination pairs (s | t << 8), sorted by t then s
+  // Branch-parallel triangular solves: the dofs behind the root chain (the free joint's 6 dofs) split into independent
+  // branches (abdomen chain, head subtree, wings, halteres); br_seq[w][lane] packs, 4 bytes per word, the elimination order
+  // (leaf end first) of the branch the lane's dof belongs to, 0xff-padded; root-chain lanes and idle lanes hold 0xff only.
+  const unsigned int FFE_GLOBAL *br_seq;   // [4][64]
+  int nbr_steps, nroot;                    // longest branch sequence; dofs of the root chain (6)
   const float FFE_GLOBAL *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
       *d_act_coef, *d_qpos0;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
   // per link
@@ -166,7 +171,7 @@ struct HostModel {
       p = (P)((size_t)base + (size_t)p);  // C-style: the member may carry a device address-space qualifier
     };
     fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
-    fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
+    fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.br_seq); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
     fix(dst.d_sref); fix(dst.d_lo); fix(dst.d_hi); fix(dst.d_margin); fix(dst.d_invw); fix(dst.d_K); fix(dst.d_B);
     fix(dst.d_solimp); fix(dst.d_act_coef); fix(dst.d_qpos0);
     fix(dst.l_anc); fix(dst.l_parent); fix(dst.l_dofadr); fix(dst.l_dofnum); fix(dst.l_sub); fix(dst.l_reckind); fix(dst.l_recell);
@@ -282,6 +287,25 @@ inline HostModel build_host_model(const Blob &b) {
       for (int sidx = 1; sidx <= t && p < 4 * kWave; sidx++) pairtab[p++] = static_cast<unsigned>(sidx) | (static_cast<unsigned>(t) << 8);
   }
   if ((maxdepth - 1) * maxdepth / 2 > 4 * kWave) throw std::runtime_error("dof chains too deep for the pair table");
+  // root chain = the free joint's dofs 0..5 (each the parent of the next); every other dof hangs off dof 5 through a branch
+  std::vector<unsigned int> br_seq(4 * kWave, 0xffffffffu);
+  int nroot = 0, nbr_steps = 0;
+  {
+    while (nroot < nv && dofpar.i(nroot) == nroot - 1 && d_ndesc[nroot] == nv - 1 - nroot) nroot++;
+    if (nroot != 6) throw std::runtime_error("expected a 6-dof root chain (free joint) ahead of the branches");
+    for (int d = nroot; d < nv; d++) {
+      if (dofpar.i(d) != nroot - 1) continue;          // d starts a branch: dofs d .. d + ndesc
+      const int len = d_ndesc[d] + 1;
+      if (len > 16) throw std::runtime_error("branch longer than the 16-step solve sequence");
+      nbr_steps = len > nbr_steps ? len : nbr_steps;
+      for (int e = d; e < d + len; e++)
+        for (int t = 0; t < len; t++) {               // elimination order: highest dof index first (descendants before ancestors)
+          unsigned int &w = br_seq[(t >> 2) * kWave + e];
+          w = (w & ~(0xffu << (8 * (t & 3)))) | (static_cast<unsigned>(d + len - 1 - t) << (8 * (t & 3)));
+        }
+    }
+  }
+  V.nbr_steps = nbr_steps; V.nroot = nroot;
   const int nM = static_cast<int>(m_row.size());
   if (nM > kMaxM) throw std::runtime_error("mass matrix exceeds kernel capacity");
   V.nM = nM;
@@ -452,7 +476,7 @@ inline HostModel build_host_model(const Blob &b) {
   set_off(V.d_madr, A.put(d_madr)); set_off(V.d_depth, A.put(d_depth));
   set_off(V.d_kind, A.put(d_kind)); set_off(V.d_qadr, A.put(d_qadr));
   set_off(V.d_limited, A.put(d_limited)); set_off(V.d_act_id, A.put(d_act_id));
-  set_off(V.d_ndesc, A.put(d_ndesc)); set_off(V.pairtab, A.put(pairtab));
+  set_off(V.d_ndesc, A.put(d_ndesc)); set_off(V.pairtab, A.put(pairtab)); set_off(V.br_seq, A.put(br_seq));
   set_off(V.d_axis, A.put(d_axis)); set_off(V.d_arm, A.put(d_arm));
   set_off(V.d_damp, A.put(d_damp)); set_off(V.d_stiff, A.put(d_stiff));
   set_off(V.d_sref, A.put(d_sref)); set_off(V.d_lo, A.put(d_lo));

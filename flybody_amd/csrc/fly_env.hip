@@ -308,6 +308,7 @@ struct Ctx {
   float qacc;         // constrained acceleration (mj: d->qacc)
   float dinv[2];      // 1 / D of this lane's dof for the two resident factorisations
   unsigned la_pack;   // this lane's row start | depth << 10 | descendant count << 16 (read by every factor / solve)
+  unsigned seq0, seq1, seq2, seq3;  // elimination order of the lane's branch, a byte per step (DevModel::br_seq)
 #ifdef FFE_STAMPS
   unsigned long long st_t0, st_acc[16];
 #endif
@@ -362,7 +363,7 @@ enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 
 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
-__device__ void stage1(Ctx &c) {
+__device__ __forceinline__ void stage1(Ctx &c) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -616,7 +617,7 @@ __device__ void stage1(Ctx &c) {
 // LDS instruction count and all index arithmetic are those of a single factorisation.  Non-DUAL refactors slot .x only
 // (an active-set change) and leaves the Euler factor in .y untouched.
 template <bool DUAL>
-__device__ void factor(Ctx &c, float add0, float add1) {
+__device__ __forceinline__ void factor(Ctx &c, float add0, float add1) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -701,7 +702,7 @@ __device__ void factor(Ctx &c, float add0, float add1) {
 // mj: mj_solveLD with the factor above; the vector lives in registers (one dof per lane) and travels by readlane,
 // the factor is only read, so there is no barrier inside the two sweeps.
 template <int COMP>
-__device__ float solve(Ctx &c, float rhs) {
+__device__ __forceinline__ float solve(Ctx &c, float rhs) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -763,7 +764,7 @@ __device__ float solve(Ctx &c, float rhs) {
 // solve both against the same right-hand side f, with the leaf-to-root substitution (x <- L^-T x) folded into the
 // elimination sweep - pivot k's row and x_k are final exactly when the sweep reaches k, so each pivot also pushes
 // x_k to its ancestors.  Saves the 41 dependent steps of a separate forward substitution.
-__device__ float2 factor_solve_both(Ctx &c, float hB, float rhs) {
+__device__ __forceinline__ float2 factor_solve_both(Ctx &c, float hB, float rhs) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -860,7 +861,7 @@ __device__ float2 factor_solve_both(Ctx &c, float hB, float rhs) {
 // Both resident factors applied to the same right-hand side in one pair of sweeps (float2 factor entries, shared
 // predicates and index arithmetic): used when no joint limit is instantiated, where qacc = M^-1 f and the Euler
 // acceleration (M + h B)^-1 f differ only in the factor.
-__device__ float2 solve_both(Ctx &c, float rhs) {
+__device__ __forceinline__ float2 solve_both(Ctx &c, float rhs) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -911,9 +912,112 @@ __device__ float2 solve_both(Ctx &c, float rhs) {
 }
 
 
+// mj: mj_solveLD, branch-parallel.  Behind the free joint's root chain (dofs 0..5) the dof tree splits into independent
+// branches (abdomen chain 14, head subtree 14, wings 3 + 3, halteres 1 + 1), so the leaf-to-root substitution runs all branches
+// at once: in step t every lane looks at the t-th pivot of ITS OWN branch (a byte of c.seq) and fetches that pivot's value
+// from the owning lane with ds_bpermute - 14 steps instead of 41, each a handful of instructions.  The root chain is then
+// coupled through six wave sums and finished with five uniform steps; the way back down mirrors it.
+// MODE 0: factor .x only; 1: factor .y only; 2: both factors on the same right-hand side (returned as .x / .y).
+__device__ __forceinline__ float bperm_f(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+__device__ __forceinline__ int bperm_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+template <int MODE>
+__device__ __forceinline__ float2 bsolve(Ctx &c, float rhs) {
+  const DevModel FFE_CONST &M = *c.Mp;  // (three uniform scalars only: no need to launder the table pointer here)
+  Tile &T = c.T;
+  const int lane = c.lane;
+  const int nv = M.nv, nroot = M.nroot, nbr = M.nbr_steps;
+  const bool is_dof = lane < nv, branch = is_dof && lane >= nroot;
+  const int d_madr = c.la_pack & 0x3ff, dep = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
+  const int my_end = lane + d_ndesc, my_md = d_madr + dep;
+  const float di0 = c.dinv[0], di1 = c.dinv[1];
+  constexpr bool U0 = MODE != 1, U1 = MODE != 0;
+  const float2 z2 = make_float2(0.f, 0.f);
+  auto ldf = [&](int e) -> float2 {  // factor entry e, only the component(s) this instantiation uses
+    if (MODE == 2) return T.LD[e];
+    const float *p = reinterpret_cast<const float *>(T.LD) + 2 * e;
+    return MODE == 0 ? make_float2(p[0], 0.f) : make_float2(0.f, p[1]);
+  };
+  if (c.flags & DBG_SKIP_SOLVE) return is_dof ? make_float2(rhs * di0, rhs * di1) : z2;
+  STAMP(6);
+  float x0 = is_dof ? rhs : 0.f, x1 = x0;
+  // ---- x <- L^-T x, branches: step t eliminates the t-th pivot of every branch
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const unsigned word = w == 0 ? c.seq0 : (w == 1 ? c.seq1 : (w == 2 ? c.seq2 : c.seq3));
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      if (4 * w + b < nbr) {  // wave-uniform
+        const int p = (int)((word >> (8 * b)) & 0xffu);
+        const bool anc = branch && lane < p && p <= my_end;  // (0xff padding never passes)
+        const int md_p = bperm_i(my_md, p);
+        const float2 l = anc ? ldf(md_p - dep) : z2;
+        if (U0) x0 -= l.x * bperm_f(x0 * di0, p);
+        if (U1) x1 -= l.y * bperm_f(x1 * di1, p);
+      }
+    }
+  }
+  // ---- root chain: every branch dof i feeds root dof r with L(i, r) x_i / D_i
+  {
+    const float y0 = branch ? x0 * di0 : 0.f, y1 = branch ? x1 * di1 : 0.f;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      if (r < nroot) {
+        const float2 l = branch ? ldf(my_md - (r + 1)) : z2;
+        if (U0) { const float s0 = wave_sum(l.x * y0); x0 = lane == r ? x0 - s0 : x0; }
+        if (U1) { const float s1 = wave_sum(l.y * y1); x1 = lane == r ? x1 - s1 : x1; }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 5; i > 0; i--) {
+    if (i < nroot) {
+      const float2 l = lane < i ? ldf(rl_i(my_md, i) - dep) : z2;
+      if (U0) x0 -= l.x * (rl_f(x0, i) * rl_f(di0, i));
+      if (U1) x1 -= l.y * (rl_f(x1, i) * rl_f(di1, i));
+    }
+  }
+  // ---- x <- D^-1 x
+  x0 *= di0; x1 *= di1;
+  // ---- x <- L^-1 x: root chain, root -> branches, then down the branches (the sequences backwards)
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    if (j + 1 < nroot) {
+      const float2 l = (lane > j && lane < nroot) ? ldf(my_md - (j + 1)) : z2;
+      if (U0) x0 -= l.x * di0 * rl_f(x0, j);
+      if (U1) x1 -= l.y * di1 * rl_f(x1, j);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    if (r < nroot) {
+      const float2 l = branch ? ldf(my_md - (r + 1)) : z2;
+      if (U0) x0 -= l.x * di0 * rl_f(x0, r);
+      if (U1) x1 -= l.y * di1 * rl_f(x1, r);
+    }
+  }
+  const int pk = my_end | (dep << 8);
+#pragma unroll
+  for (int w = 3; w >= 0; w--) {
+    const unsigned word = w == 0 ? c.seq0 : (w == 1 ? c.seq1 : (w == 2 ? c.seq2 : c.seq3));
+#pragma unroll
+    for (int b = 3; b >= 0; b--) {
+      if (4 * w + b < nbr) {
+        const int q = (int)((word >> (8 * b)) & 0xffu);
+        const int pq = bperm_i(pk, q);
+        const bool desc = branch && q < lane && lane <= (pq & 0xff);
+        const float2 l = desc ? ldf(my_md - (pq >> 8)) : z2;
+        if (U0) x0 -= l.x * di0 * bperm_f(x0, q);
+        if (U1) x1 -= l.y * di1 * bperm_f(x1, q);
+      }
+    }
+  }
+  STAMP(7);
+  return make_float2(x0, x1);
+}
+
 // Stage 2 = mj_fwdActuation, mj_fwdAcceleration, mj_fwdConstraint (joint limits), accelerometer, mj_Euler.
 // `ctrl_force` is the per-dof generalized actuator force, already assembled.
-__device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, double ghost_accel_z, unsigned long long &lo_mask,
+__device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, double ghost_accel_z, unsigned long long &lo_mask,
                      unsigned long long &hi_mask, int &iters_out) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
@@ -960,12 +1064,18 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, do
   const float hB = (is_dof && want_euler) ? h * M.d_damp[lane] : 0.f;
   if (ex_any == 0ULL) {
     // no limit instantiated: one dual factorisation, one dual solve
+#ifdef FFE_OLD_SOLVE
     if (want_euler && !(c.flags & (DBG_SKIP_FACTOR | DBG_SKIP_SOLVE))) { const float2 r = factor_solve_both(c, hB, f); a = r.x; ae = r.y; }
     else {
       factor<true>(c, 0.f, hB);
       if (want_euler) { const float2 r = solve_both(c, f); a = r.x; ae = r.y; }
       else { a = solve<0>(c, f); ae = a; }
     }
+#else
+    factor<true>(c, 0.f, hB);
+    if (want_euler) { const float2 r = bsolve<2>(c, f); a = r.x; ae = r.y; }
+    else { a = bsolve<0>(c, f).x; ae = a; }
+#endif
   } else {
 #pragma unroll 1
     for (int it = 0; it < 8; it++) {
@@ -973,7 +1083,11 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, do
       const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
       if (it == 0) factor<true>(c, add, hB);   // constraint Hessian and Euler matrix in one sweep
       else factor<false>(c, add, 0.f);          // active set changed: refactor the Hessian only
+#ifdef FFE_OLD_SOLVE
       a = solve<0>(c, rhs);
+#else
+      a = bsolve<0>(c, rhs).x;
+#endif
       iters++;
       const bool n_lo = ex_lo && (a - ar_lo < 0.f);
       const bool n_hi = ex_hi && (-a - ar_hi < 0.f);
@@ -983,7 +1097,11 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, do
     }
     if (act_lo) fc += D_lo * (ar_lo - a);
     if (act_hi) fc -= D_hi * (ar_hi + a);
+#ifdef FFE_OLD_SOLVE
     ae = want_euler ? solve<1>(c, f + fc) : a;
+#else
+    ae = want_euler ? bsolve<1>(c, f + fc).y : a;
+#endif
   }
   STAMP(14);  // (remaining glue inside the constraint/Euler block)
   lo_mask = __ballot(act_lo);
@@ -1037,7 +1155,7 @@ __device__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, do
 }
 
 // mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.
-__device__ float actuation(Ctx &c, const float *ctrl_lds) {
+__device__ __forceinline__ float actuation(Ctx &c, const float *ctrl_lds) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -1111,7 +1229,7 @@ __device__ __forceinline__ ObsLayout obs_layout(int nj, int nref) {
 
 // Observation assembly (ref: fruitfly.py:532-708 enabled set per tasks/base.py:167-168 + flight_imitation.py:84-85;
 // ref_displacement / ref_root_quat: tasks/base.py:237-261).  Returns |ref_displacement[0]| and ref_root_quat[0].
-__device__ void write_obs(Ctx &c, const TaskDev FFE_CONST &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_row0, int step_counter,
+__device__ __forceinline__ void write_obs(Ctx &c, const TaskDev FFE_CONST &K, float *obs, V3 s_acc, V3 s_gyro, V3 s_vel, int traj_row0, int step_counter,
                           float &com_dist, Q4 &rq0) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
@@ -1148,6 +1266,7 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
   const DevModel FFE_CONST &M = *c.Mp;
   c.dinv[0] = c.dinv[1] = 0.f;
   c.la_pack = (unsigned)M.d_madr[c.lane] | ((unsigned)M.d_depth[c.lane] << 10) | ((unsigned)M.d_ndesc[c.lane] << 16);
+  c.seq0 = M.br_seq[c.lane]; c.seq1 = M.br_seq[kWave + c.lane]; c.seq2 = M.br_seq[2 * kWave + c.lane]; c.seq3 = M.br_seq[3 * kWave + c.lane];
   for (int e = c.lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
 }
 
@@ -1172,7 +1291,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   }
   const int lane = threadIdx.x;
   EnvState &S = states[env];
-  Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}, 0u};
+  Ctx c{Mp, T, lane, K.flags, V3{0.f, 0.f, 0.f}, 0.f, 0.f, {0.f, 0.f}, 0u, 0u, 0u, 0u, 0u};
 #ifdef FFE_STAMPS
   c.st_t0 = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < 16; k++) c.st_acc[k] = 0;
