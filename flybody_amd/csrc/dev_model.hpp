@@ -95,6 +95,7 @@ struct DevModel {
   // (leaf end first) of the branch the lane's dof belongs to, 0xff-padded; root-chain lanes and idle lanes hold 0xff only.
   const unsigned int FFE_GLOBAL *br_seq;   // [4][64]
   int nbr_steps, nroot;                    // longest branch sequence; dofs of the root chain (6)
+  int any_b2;                              // some actuator has a velocity term in its affine bias (none in the flight model)
   const float FFE_GLOBAL *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
       *d_act_coef, *d_qpos0;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
   // per link
@@ -107,12 +108,13 @@ struct DevModel {
   const float FFE_GLOBAL *ell;
   // sparse-M index tables
   const unsigned char FFE_GLOBAL *m_row, *m_col;
+  const unsigned short FFE_GLOBAL *colmadr;  // [nM] for entry e = (row k, column a): start of row a
   // actuators
   const int FFE_GLOBAL *a_cl, *a_fl, *a_action, *t_qadr, *t_dof;
   const float FFE_GLOBAL *t_coef;
   const float FFE_GLOBAL *a_gain, *a_b0, *a_b1, *a_b2, *a_clo, *a_chi, *a_flo, *a_fhi;
   // task bookkeeping
-  const int FFE_GLOBAL *wing_dof, *wing_qadr, *wing_action, *obsj_qadr, *obsj_dof;
+  const int FFE_GLOBAL *wing_dof, *wing_qadr, *wing_action, *wing_ctrl, *obsj_qadr, *obsj_dof;  // wing_ctrl: ctrl slot fed by the wing's action entry
   int user_action;
   const float FFE_GLOBAL *qpos0;  // [nq]
 };
@@ -178,11 +180,11 @@ struct HostModel {
     fix(dst.l_pos); fix(dst.l_quat); fix(dst.l_ipos); fix(dst.l_imat); fix(dst.l_inertia); fix(dst.l_mass);
     fix(dst.l_recpos); fix(dst.l_recmat); fix(dst.l_reccoef);
     fix(dst.rr_pos); fix(dst.rr_mat); fix(dst.rr_coef); fix(dst.ell);
-    fix(dst.m_row); fix(dst.m_col);
+    fix(dst.m_row); fix(dst.m_col); fix(dst.colmadr);
     fix(dst.a_cl); fix(dst.a_fl); fix(dst.a_action); fix(dst.t_qadr); fix(dst.t_dof); fix(dst.t_coef);
     fix(dst.a_gain); fix(dst.a_b0); fix(dst.a_b1); fix(dst.a_b2); fix(dst.a_clo); fix(dst.a_chi); fix(dst.a_flo);
     fix(dst.a_fhi);
-    fix(dst.wing_dof); fix(dst.wing_qadr); fix(dst.wing_action); fix(dst.obsj_qadr); fix(dst.obsj_dof);
+    fix(dst.wing_dof); fix(dst.wing_qadr); fix(dst.wing_action); fix(dst.wing_ctrl); fix(dst.obsj_qadr); fix(dst.obsj_dof);
     fix(dst.qpos0);
   }
 };
@@ -437,6 +439,8 @@ inline HostModel build_host_model(const Blob &b) {
     } else throw std::runtime_error("body (adhesion) transmissions are not supported yet");
   }
   for (int u = nu; u <= kMaxAct; u++) a_wrap_off[u] = static_cast<int>(w_qadr.size());
+  V.any_b2 = 0;
+  for (int u = 0; u < nu; u++) if (a_b2[u] != 0.f) V.any_b2 = 1;
   // transposed, zero-padded transmission table [term][actuator]: every actuator - joint or tendon driven - is a sum of
   // up to kMaxWrap (coef, dof) terms, so the kernel evaluates length and velocity without a data-dependent loop
   std::vector<int> t_qadr(kMaxWrap * kMaxAct, 0), t_dof(kMaxWrap * kMaxAct, 0);
@@ -458,7 +462,17 @@ inline HostModel build_host_model(const Blob &b) {
   const Tensor &wing_jnt = b.get("wing_jnt"), &wing_act = b.get("wing_action"), &obs_jnt = b.get("obs_jnt");
   std::vector<int> wing_dof(8, 0), wing_qadr(8, 0), wing_action(8, 0), obsj_qadr(kMaxObsJ, 0), obsj_dof(kMaxObsJ, 0);
   V.nwing = static_cast<int>(wing_jnt.count);
-  for (int k = 0; k < V.nwing; k++) { wing_dof[k] = jnt_dadr.i(wing_jnt.i(k)); wing_qadr[k] = jnt_qadr.i(wing_jnt.i(k)); wing_action[k] = wing_act.i(k); }
+  std::vector<int> wing_ctrl(8, -1);
+  for (int k = 0; k < V.nwing; k++) {
+    wing_dof[k] = jnt_dadr.i(wing_jnt.i(k)); wing_qadr[k] = jnt_qadr.i(wing_jnt.i(k)); wing_action[k] = wing_act.i(k);
+    for (int u = 0; u < nu; u++)
+      if (a_action[u] == wing_action[k]) {
+        if (wing_ctrl[k] >= 0) throw std::runtime_error("a wing action entry feeds more than one actuator");
+        wing_ctrl[k] = u;
+      }
+  }
+  std::vector<unsigned short> colmadr(m_row.size() + 8, 0);
+  for (size_t e = 0; e < m_row.size(); e++) colmadr[e] = static_cast<unsigned short>(d_madr[m_col[e]]);
   V.nobsj = static_cast<int>(obs_jnt.count);
   if (V.nobsj > kMaxObsJ) throw std::runtime_error("too many observable joints");
   for (int k = 0; k < V.nobsj; k++) { obsj_qadr[k] = jnt_qadr.i(obs_jnt.i(k)); obsj_dof[k] = jnt_dadr.i(obs_jnt.i(k)); }
@@ -495,7 +509,7 @@ inline HostModel build_host_model(const Blob &b) {
   set_off(V.l_reccoef, A.put(l_reccoef));
   set_off(V.rr_pos, A.put(rr_pos)); set_off(V.rr_mat, A.put(rr_mat));
   set_off(V.rr_coef, A.put(rr_coef)); set_off(V.ell, A.put(ell));
-  set_off(V.m_row, A.put(m_row)); set_off(V.m_col, A.put(m_col));
+  set_off(V.m_row, A.put(m_row)); set_off(V.m_col, A.put(m_col)); set_off(V.colmadr, A.put(colmadr));
   set_off(V.a_cl, A.put(a_cl));
   set_off(V.a_fl, A.put(a_fl)); set_off(V.a_action, A.put(a_action));
   set_off(V.t_qadr, A.put(t_qadr)); set_off(V.t_dof, A.put(t_dof)); set_off(V.t_coef, A.put(t_coef));
@@ -504,7 +518,7 @@ inline HostModel build_host_model(const Blob &b) {
   set_off(V.a_clo, A.put(a_clo)); set_off(V.a_chi, A.put(a_chi));
   set_off(V.a_flo, A.put(a_flo)); set_off(V.a_fhi, A.put(a_fhi));
   set_off(V.wing_dof, A.put(wing_dof)); set_off(V.wing_qadr, A.put(wing_qadr));
-  set_off(V.wing_action, A.put(wing_action));
+  set_off(V.wing_action, A.put(wing_action)); set_off(V.wing_ctrl, A.put(wing_ctrl));
   set_off(V.obsj_qadr, A.put(obsj_qadr)); set_off(V.obsj_dof, A.put(obsj_dof));
   set_off(V.qpos0, A.put(qpos0));
   H.arena = A.bytes();

@@ -52,6 +52,7 @@ struct TaskDev {
   int nfreq, ntraj, future_steps, time_limit_steps, episode_limit_steps, pad_first_obs, flags, obs_dim, canonical, clip;
   float act_lo[16], act_hi[16];
   double base_freq, rel_range, rate, dt_ctrl, terminal_com_dist, ghost_accel_z;
+  double grid_inv_step;  // 1 / spacing of the beat-frequency grid when it is evenly spaced (np.linspace), else 0
   const double FFE_GLOBAL *beat_freqs, *phase, *phase_frac, *ref_qpos, *ref_qvel;
   const float FFE_GLOBAL *traj;
   const int FFE_GLOBAL *tab_off;
@@ -88,6 +89,8 @@ struct alignas(16) Tile {
   double rootpos[4];  // free-joint position in float64
   double ghost[16];   // pos[3], quat[4], vel[3], angvel[3]
 };
+
+static_assert(offsetof(Tile, cdof) % 8 == 0 && offsetof(Tile, buf) % 8 == 0 && sizeof(float[6]) % 8 == 0, "ld6a needs 8-byte aligned 6-vector rows");
 
 // ------------------------------------------------------------------------------------------------ maths
 struct V3 { float x, y, z; };
@@ -191,6 +194,13 @@ __device__ __forceinline__ S6 mul_inert(const I10 &i, S6 v) {
   return {i.i0 * v.a0 + i.i3 * v.a1 + i.i4 * v.a2 - i.i8 * v.l1 + i.i7 * v.l2, i.i3 * v.a0 + i.i1 * v.a1 + i.i5 * v.a2 + i.i8 * v.l0 - i.i6 * v.l2,
           i.i4 * v.a0 + i.i5 * v.a1 + i.i2 * v.a2 - i.i7 * v.l0 + i.i6 * v.l1, i.i8 * v.a1 - i.i7 * v.a2 + i.i9 * v.l0,
           i.i6 * v.a2 - i.i8 * v.a0 + i.i9 * v.l1, i.i7 * v.a0 - i.i6 * v.a1 + i.i9 * v.l2};
+}
+// 6-vector rows of cdof / buf start on 8-byte boundaries (24-byte rows at 8-aligned offsets of the 16-aligned tile): three
+// ds_read_b64 instead of six ds_read_b32
+__device__ __forceinline__ S6 ld6a(const float *p) {
+  const float2 *q = reinterpret_cast<const float2 *>(p);
+  const float2 a = q[0], b = q[1], c = q[2];
+  return {a.x, a.y, b.x, b.y, c.x, c.y};
 }
 __device__ __forceinline__ int rl_i(int v, int lane_idx) { return __builtin_amdgcn_readlane(v, lane_idx); }
 __device__ __forceinline__ float rl_f(float v, int lane_idx) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx)); }
@@ -642,7 +652,7 @@ __device__ __forceinline__ void factor(Ctx &c, float add0, float add1) {
     for (int r = 0; r < 7; r++) {
       const int e = lane + r * kWave;
       if (e < M.nM) {
-        float m = dot6(ld6(T.cdof[ej[r]]), ld6(T.buf[ei[r]]));
+        float m = dot6(ld6a(T.cdof[ej[r]]), ld6a(T.buf[ei[r]]));
         if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + ((c.flags & DBG_SKIP_MENTRIES) ? 1.f : 0.f);
         if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
       }
@@ -788,7 +798,7 @@ __device__ __forceinline__ float2 factor_solve_both(Ctx &c, float hB, float rhs)
     for (int r = 0; r < 7; r++) {
       const int e = lane + r * kWave;
       if (e < M.nM) {
-        float m = dot6(ld6(T.cdof[ej[r]]), ld6(T.buf[ei[r]]));
+        float m = dot6(ld6a(T.cdof[ej[r]]), ld6a(T.buf[ei[r]]));
         if (ei[r] == ej[r]) m += M.d_arm[ei[r]];
         T.LD[e] = make_float2(m, m);
       }
@@ -1154,8 +1164,18 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   return accel;
 }
 
-// mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.
-__device__ __forceinline__ float actuation(Ctx &c, const float *ctrl_lds) {
+// mj: mj_fwdActuation.  Returns the generalized actuator force on this lane's dof.  `abase` = gain * clamp(ctrl) + bias0 of
+// this lane's actuator: the control is fixed over a control step, so that part is evaluated once per launch (actuation_base);
+// per substep only the length / velocity terms of the affine bias remain (velocity only if some actuator has a bias2).
+__device__ __forceinline__ float actuation_base(Ctx &c, float ctrl) {
+  const DevModel FFE_CONST &M = model(c);
+  const int lane = c.lane;
+  if ((c.flags & FFE_NO_ACTUATION) || lane >= M.nu) return 0.f;
+  const float clo = M.a_clo[lane], chi = M.a_chi[lane];
+  ctrl = M.a_cl[lane] ? fminf(fmaxf(ctrl, clo), chi) : ctrl;
+  return M.a_gain[lane] * ctrl + M.a_b0[lane];
+}
+__device__ __forceinline__ float actuation(Ctx &c, float abase) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -1164,20 +1184,19 @@ __device__ __forceinline__ float actuation(Ctx &c, const float *ctrl_lds) {
     // phase 1: every table read of this actuator is issued before anything waits (independent addresses)
     int tq[kMaxWrap], td[kMaxWrap];
     float tc[kMaxWrap];
+    const bool use_vel = M.any_b2 != 0;  // uniform
 #pragma unroll
     for (int w = 0; w < kMaxWrap; w++) {  // zero-padded transmission terms: joint actuators have one, fixed tendons several
-      tq[w] = M.t_qadr[w * kMaxAct + lane]; td[w] = M.t_dof[w * kMaxAct + lane]; tc[w] = M.t_coef[w * kMaxAct + lane];
+      tq[w] = M.t_qadr[w * kMaxAct + lane]; tc[w] = M.t_coef[w * kMaxAct + lane];
+      td[w] = use_vel ? M.t_dof[w * kMaxAct + lane] : 0;
     }
-    const int cl = M.a_cl[lane], fl = M.a_fl[lane];
-    const float clo = M.a_clo[lane], chi = M.a_chi[lane], gain = M.a_gain[lane], b0 = M.a_b0[lane], b1 = M.a_b1[lane], b2 = M.a_b2[lane],
-                flo = M.a_flo[lane], fhi = M.a_fhi[lane];
+    const int fl = M.a_fl[lane];
+    const float b1 = M.a_b1[lane], b2 = use_vel ? M.a_b2[lane] : 0.f, flo = M.a_flo[lane], fhi = M.a_fhi[lane];
     // phase 2
-    float ctrl = ctrl_lds[lane];
-    ctrl = cl ? fminf(fmaxf(ctrl, clo), chi) : ctrl;
     float len = 0.f, vel = 0.f;
 #pragma unroll
-    for (int w = 0; w < kMaxWrap; w++) { len += tc[w] * T.qpos[tq[w]]; vel += tc[w] * T.qvel[td[w]]; }
-    float force = gain * ctrl + b0 + b1 * len + b2 * vel;
+    for (int w = 0; w < kMaxWrap; w++) { len += tc[w] * T.qpos[tq[w]]; if (use_vel) vel += tc[w] * T.qvel[td[w]]; }
+    float force = abase + b1 * len + b2 * vel;
     force = fl ? fminf(fmaxf(force, flo), fhi) : force;
     T.frc[lane] = force;
   }
@@ -1217,6 +1236,20 @@ __device__ int wave_argmin_absdiff(const double FFE_GLOBAL *tab, int n, double x
     int oi = __shfl_xor(bi, o);
     if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
+  return bi;
+}
+
+// argmin_i |table[i] - x| on a monotone, evenly spaced table (np.linspace: the 201 beat frequencies): the nearest grid point
+// by arithmetic, then an exact comparison of it and its two neighbours with numpy's first-minimum tie-break.  Identical to
+// the full scan whenever the table is within a quarter step of uniform, which the host checks (else grid_inv_step = 0).
+__device__ __forceinline__ int grid_argmin_absdiff(const double FFE_GLOBAL *tab, int n, double x, double inv_step) {
+  int k = (int)rint((x - tab[0]) * inv_step);
+  k = k < 1 ? 1 : (k > n - 2 ? n - 2 : k);
+  const double v0 = fabs(x - tab[k - 1]), v1 = fabs(x - tab[k]), v2 = fabs(x - tab[k + 1]);
+  int bi = k - 1;
+  double bv = v0;
+  if (v1 < bv) { bv = v1; bi = k; }
+  if (v2 < bv) { bv = v2; bi = k + 1; }
   return bi;
 }
 
@@ -1267,7 +1300,7 @@ __device__ __forceinline__ void load_lane_consts(Ctx &c) {
   c.dinv[0] = c.dinv[1] = 0.f;
   c.la_pack = (unsigned)M.d_madr[c.lane] | ((unsigned)M.d_depth[c.lane] << 10) | ((unsigned)M.d_ndesc[c.lane] << 16);
   c.seq0 = M.br_seq[c.lane]; c.seq1 = M.br_seq[kWave + c.lane]; c.seq2 = M.br_seq[2 * kWave + c.lane]; c.seq3 = M.br_seq[3 * kWave + c.lane];
-  for (int e = c.lane; e < M.nM; e += kWave) c.T.colmadr[e] = (unsigned short)M.d_madr[M.m_col[e]];
+  for (int e = c.lane; e < M.nM; e += kWave) c.T.colmadr[e] = M.colmadr[e];  // (host table: no dependent index chase at launch)
 }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
@@ -1371,7 +1404,9 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
       wb_step = (wb_step + 1) % len;
       wb_cf = wbpg_filter(wb_cf, K.rate, K.base_freq, K.rel_range, (double)act_user);
-      int idx_new = (c.flags & DBG_SKIP_WBPG) ? wb_idx : wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane);
+      int idx_new = (c.flags & DBG_SKIP_WBPG) ? wb_idx
+                    : (K.grid_inv_step > 0.0 ? grid_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, K.grid_inv_step)
+                                             : wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane));
       if (idx_new != wb_idx) {
         double cur = K.phase_frac[off + wb_step];
         int noff = K.tab_off[idx_new], nlen = K.tab_off[idx_new + 1] - noff;
@@ -1388,7 +1423,8 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       // action[wings] += target - qpos[wing]; the wing actuators are the ctrl slots fed by those action entries
       float tgt = K.traj[(size_t)(K.tab_off[wb_idx] + wb_step) * 6 + lane];
       float add = tgt - T.qpos[M.wing_qadr[lane]];
-      for (int u = 0; u < M.nu; u++) if (M.a_action[u] == M.wing_action[lane]) T.ctrl[u] += add;
+      const int u = M.wing_ctrl[lane];  // the ctrl slot fed by this wing's action entry
+      if (u >= 0) T.ctrl[u] += add;
     }
     SYNC();
     ctrl_reg = lane < M.nu ? T.ctrl[lane] : 0.f;
@@ -1402,6 +1438,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   // ---- physics.  dm_control's legacy step is mj_step2 then mj_step1, so the position/velocity stage is evaluated
   //      once up front and again after every integration; buffered sensors take one sample per substep.  A reset
   //      is the same pipeline run once without actuation and without integrating (mj_forward).
+  const float abase = do_reset ? 0.f : actuation_base(c, ctrl_reg);
   STAMP(11);  // prologue: state load, WBPG, action mixing (or episode reset)
   const bool have_saved = !do_reset && S.s1_valid != 0 && !(c.flags & DBG_NO_CARRY);
   const int nst = do_reset ? 1 : nsub;
@@ -1423,11 +1460,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     }
     if (s == nst) break;
     float qa = 0.f;
-    if (!do_reset) {
-      if (lane < M.nu) T.frc[lane] = ctrl_reg;
-      SYNC();
-      qa = actuation(c, T.frc);
-    }
+    if (!do_reset) qa = actuation(c, abase);
     STAMP(12);  // sensor accumulation + actuation
     int it = 0;
     const V3 acc = stage2(c, qa, !do_reset, !do_reset && !phys_only && !(c.flags & DBG_SKIP_GHOST), K.ghost_accel_z, lo_mask, hi_mask, it);
@@ -1697,6 +1730,13 @@ int ffe_create_flight(const void *model_blob, size_t blob_size, const ffe_flight
     for (int k = 0; k < 16; k++) { K.act_lo[k] = k < h->dm.naction ? h->host.action_min[k] : 0.f; K.act_hi[k] = k < h->dm.naction ? h->host.action_max[k] : 0.f; }
     K.base_freq = t.wb_base_freq; K.rel_range = t.wb_rel_range; K.rate = t.wb_rate; K.dt_ctrl = t.wb_dt_ctrl;
     K.terminal_com_dist = t.terminal_com_dist; K.ghost_accel_z = t.ghost_accel_z;
+    K.grid_inv_step = 0.0;
+    if (t.wb_nfreq >= 3) {  // evenly spaced and increasing (ref: pattern_generators.py:65-69 np.linspace)? then the lookup is arithmetic
+      const double step = (t.wb_beat_freqs[t.wb_nfreq - 1] - t.wb_beat_freqs[0]) / (t.wb_nfreq - 1);
+      bool even = step > 0;
+      for (int i = 0; i < t.wb_nfreq && even; i++) even = std::fabs(t.wb_beat_freqs[i] - (t.wb_beat_freqs[0] + i * step)) < 0.25 * step;
+      if (even) K.grid_inv_step = 1.0 / step;
+    }
     set_off(K.beat_freqs, (size_t)upload(h.get(), t.wb_beat_freqs, (size_t)t.wb_nfreq));
     set_off(K.tab_off, (size_t)upload(h.get(), t.wb_tab_off, (size_t)t.wb_nfreq + 1));
     set_off(K.phase, (size_t)upload(h.get(), t.wb_phase, (size_t)rows));
