@@ -96,6 +96,13 @@ struct DevModel {
   const unsigned int FFE_GLOBAL *br_seq;   // [4][64]
   int nbr_steps, nroot;                    // longest branch sequence; dofs of the root chain (6)
   int any_b2;                              // some actuator has a velocity term in its affine bias (none in the flight model)
+  // Branch-parallel factorisation schedule: step t eliminates the t-th pivot of every branch at once; the pair updates
+  // M(a_s, a_t) -= M(k, a_s) M(k, a_t) / M(k, k) of all those pivots are dealt over the 64 lanes in rounds.  One word per
+  // (round, lane): row start of the pivot | s << 9 | t << 14 | target << 19 | last round of its step << 30 | valid << 31, the
+  // target being an entry of M, or 512 + 21 * branch + e for entry e of the root block (rows of the free joint's dofs), which
+  // concurrent branches accumulate in private copies (folded in before the root chain is eliminated).
+  const unsigned int FFE_GLOBAL *fsched;   // [fs_rounds + 1][64]
+  int fs_branch_rounds, fs_rounds, nbranch;
   const float FFE_GLOBAL *d_axis, *d_arm, *d_damp, *d_stiff, *d_sref, *d_lo, *d_hi, *d_margin, *d_invw, *d_K, *d_B, *d_solimp,
       *d_act_coef, *d_qpos0;  // d_axis [3][64]; d_solimp [5][64]; d_act_coef [2][64]
   // per link
@@ -173,7 +180,7 @@ struct HostModel {
       p = (P)((size_t)base + (size_t)p);  // C-style: the member may carry a device address-space qualifier
     };
     fix(dst.d_link); fix(dst.d_madr); fix(dst.d_depth); fix(dst.d_kind); fix(dst.d_qadr);
-    fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.br_seq); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
+    fix(dst.d_limited); fix(dst.d_act_id); fix(dst.d_ndesc); fix(dst.pairtab); fix(dst.br_seq); fix(dst.fsched); fix(dst.d_axis); fix(dst.d_arm); fix(dst.d_damp); fix(dst.d_stiff);
     fix(dst.d_sref); fix(dst.d_lo); fix(dst.d_hi); fix(dst.d_margin); fix(dst.d_invw); fix(dst.d_K); fix(dst.d_B);
     fix(dst.d_solimp); fix(dst.d_act_coef); fix(dst.d_qpos0);
     fix(dst.l_anc); fix(dst.l_parent); fix(dst.l_dofadr); fix(dst.l_dofnum); fix(dst.l_sub); fix(dst.l_reckind); fix(dst.l_recell);
@@ -308,6 +315,46 @@ inline HostModel build_host_model(const Blob &b) {
     }
   }
   V.nbr_steps = nbr_steps; V.nroot = nroot;
+  std::vector<unsigned int> fsched;
+  {
+    std::vector<int> bstart, blen;
+    for (int d = nroot; d < nv; d++) if (dofpar.i(d) == nroot - 1) { bstart.push_back(d); blen.push_back(d_ndesc[d] + 1); }
+    V.nbranch = static_cast<int>(bstart.size());
+    if (V.nbranch > 8 || d_madr[nroot] != nroot * (nroot + 1) / 2) throw std::runtime_error("unexpected branch structure behind the root chain");
+    auto anc = [&](int k, int sidx) { int a = k; for (int i = 0; i < sidx; i++) a = dofpar.i(a); return a; };
+    auto emit_step = [&](const std::vector<std::pair<int, int>> &pivots) {  // (pivot dof, branch or -1 for a root pivot)
+      std::vector<unsigned int> words;
+      for (auto [k, br] : pivots) {
+        const int n = d_depth[k] - 1;
+        for (int t = 1; t <= n; t++)
+          for (int sidx = 1; sidx <= t; sidx++) {
+            const int as = anc(k, sidx);
+            int tgt = d_madr[as] + (t - sidx);
+            if (br >= 0 && as < nroot) tgt = 512 + 21 * br + tgt;  // root block: private copy of this branch
+            if (d_madr[k] >= 512 || tgt >= 1024) throw std::runtime_error("factor schedule field overflow");
+            words.push_back(static_cast<unsigned>(d_madr[k]) | (static_cast<unsigned>(sidx) << 9) | (static_cast<unsigned>(t) << 14) |
+                            (static_cast<unsigned>(tgt) << 19) | 0x80000000u);
+          }
+      }
+      const size_t rounds = (words.size() + kWave - 1) / kWave;
+      for (size_t r = 0; r < rounds; r++)
+        for (int l = 0; l < kWave; l++) {
+          const size_t i = r * kWave + l;
+          unsigned w = i < words.size() ? words[i] : 0u;
+          if (r + 1 == rounds) w |= 0x40000000u;  // (every lane of the round carries the flag)
+          fsched.push_back(w);
+        }
+    };
+    for (int t = 0; t < nbr_steps; t++) {
+      std::vector<std::pair<int, int>> piv;
+      for (int bi = 0; bi < V.nbranch; bi++) if (t < blen[bi]) piv.push_back({bstart[bi] + blen[bi] - 1 - t, bi});
+      emit_step(piv);
+    }
+    V.fs_branch_rounds = static_cast<int>(fsched.size() / kWave);
+    for (int k = nroot - 1; k > 0; k--) emit_step({{k, -1}});
+    V.fs_rounds = static_cast<int>(fsched.size() / kWave);
+    for (int l = 0; l < 2 * kWave; l++) fsched.push_back(0u);  // read-ahead padding
+  }
   const int nM = static_cast<int>(m_row.size());
   if (nM > kMaxM) throw std::runtime_error("mass matrix exceeds kernel capacity");
   V.nM = nM;
@@ -490,7 +537,7 @@ inline HostModel build_host_model(const Blob &b) {
   set_off(V.d_madr, A.put(d_madr)); set_off(V.d_depth, A.put(d_depth));
   set_off(V.d_kind, A.put(d_kind)); set_off(V.d_qadr, A.put(d_qadr));
   set_off(V.d_limited, A.put(d_limited)); set_off(V.d_act_id, A.put(d_act_id));
-  set_off(V.d_ndesc, A.put(d_ndesc)); set_off(V.pairtab, A.put(pairtab)); set_off(V.br_seq, A.put(br_seq));
+  set_off(V.d_ndesc, A.put(d_ndesc)); set_off(V.pairtab, A.put(pairtab)); set_off(V.br_seq, A.put(br_seq)); set_off(V.fsched, A.put(fsched));
   set_off(V.d_axis, A.put(d_axis)); set_off(V.d_arm, A.put(d_arm));
   set_off(V.d_damp, A.put(d_damp)); set_off(V.d_stiff, A.put(d_stiff));
   set_off(V.d_sref, A.put(d_sref)); set_off(V.d_lo, A.put(d_lo));

@@ -922,6 +922,102 @@ __device__ __forceinline__ float2 solve_both(Ctx &c, float rhs) {
 }
 
 
+// mj: mj_factorI, branch-parallel (same tree-sparse L'DL, same row layout and 1/D convention as `factor` above).  The dofs
+// behind the free joint's root chain split into independent branches, so step t eliminates the t-th pivot of EVERY branch:
+// 14 dependent steps + 5 for the root chain instead of 41.  The pair updates of a step's pivots are dealt over the 64 lanes in
+// rounds by a host-built schedule (DevModel::fsched, one coalesced word per lane and round, fetched one round ahead);
+// updates of the root block (rows of the free joint's dofs), which every branch touches, go to a private copy per branch
+// (in the link scratch arrays, idle during stage 2) and are folded in before the root chain is eliminated.
+static_assert(offsetof(Tile, la) % 8 == 0 && sizeof(Tile::la) + sizeof(Tile::lb) + sizeof(Tile::lc) >= 8 * 21 * 8, "root-block copies of up to 8 branches");
+template <bool DUAL>
+__device__ __forceinline__ void bfactor(Ctx &c, float add0, float add1) {
+  const DevModel FFE_CONST &M = model(c);
+  Tile &T = c.T;
+  const int lane = c.lane;
+  const int nv = M.nv;
+  const int d_madr = c.la_pack & 0x3ff;
+  STAMP(6);
+  {  // mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs, written straight into the working copy
+    int ei[7], ej[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const int e = lane + r * kWave;
+      const bool ok = e < M.nM;
+      ei[r] = ok ? M.m_row[e] : 0;
+      ej[r] = ok ? M.m_col[e] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const int e = lane + r * kWave;
+      if (e < M.nM) {
+        float m = dot6(ld6a(T.cdof[ej[r]]), ld6a(T.buf[ei[r]]));
+        if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + ((c.flags & DBG_SKIP_MENTRIES) ? 1.f : 0.f);
+        if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
+      }
+    }
+  }
+  float2 *dl = reinterpret_cast<float2 *>(&T.la[0][0]);
+  const int ndl = 21 * M.nbranch;
+  for (int e = lane; e < ndl; e += kWave) dl[e] = make_float2(0.f, 0.f);
+  SYNC();
+  if (lane < nv) {
+    T.LD[d_madr].x += add0;
+    if (DUAL) T.LD[d_madr].y += add1;
+  }
+  SYNC();
+  STAMP(4);  // M entries
+  if (!(c.flags & DBG_SKIP_FACTOR)) {
+    const unsigned FFE_GLOBAL *tab = M.fsched + lane;
+    const int nbr_rounds = M.fs_branch_rounds, nrounds = M.fs_rounds;
+    auto round = [&](unsigned w) {
+      if (w >> 31) {
+        const int mk = (int)(w & 0x1ffu), sidx = (int)((w >> 9) & 0x1fu), tidx = (int)((w >> 14) & 0x1fu), tg = (int)((w >> 19) & 0x3ffu);
+        float2 *tp = tg < 512 ? &T.LD[tg] : &dl[tg - 512];
+        if (DUAL) {
+          const float2 piv = T.LD[mk], a = T.LD[mk + sidx], b = T.LD[mk + tidx];
+          float2 t = *tp;
+          t.x -= a.x * __builtin_amdgcn_rcpf(piv.x) * b.x;
+          t.y -= a.y * __builtin_amdgcn_rcpf(piv.y) * b.y;
+          *tp = t;
+        } else {
+          tp->x -= T.LD[mk + sidx].x * __builtin_amdgcn_rcpf(T.LD[mk].x) * T.LD[mk + tidx].x;
+        }
+      }
+    };
+    unsigned w = tab[0];
+#pragma unroll 1
+    for (int r = 0; r < nbr_rounds; r++) {
+      const unsigned wn = tab[(r + 1) * kWave];
+      round(w);
+      if (__builtin_amdgcn_readfirstlane(w) & 0x40000000u) SYNC();  // last round of a step: the next pivots read what this step wrote
+      w = wn;
+    }
+    SYNC();
+    // fold the branches' root-block copies into the root rows, then eliminate the root chain
+    if (lane < 21) {
+      float2 acc = T.LD[lane];
+      for (int b = 0; b < M.nbranch; b++) { const float2 d = dl[21 * b + lane]; acc.x += d.x; if (DUAL) acc.y += d.y; }
+      if (DUAL) T.LD[lane] = acc; else T.LD[lane].x = acc.x;
+    }
+    SYNC();
+#pragma unroll 1
+    for (int r = nbr_rounds; r < nrounds; r++) {
+      const unsigned wn = tab[(r + 1) * kWave];
+      round(w);
+      SYNC();
+      w = wn;
+    }
+  }
+  if (DUAL) {
+    const float2 d = T.LD[d_madr];
+    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(d.x) : 0.f;
+    c.dinv[1] = lane < nv ? __builtin_amdgcn_rcpf(d.y) : 0.f;
+  } else {
+    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(T.LD[d_madr].x) : 0.f;
+  }
+  STAMP(5);  // elimination
+}
+
 // mj: mj_solveLD, branch-parallel.  Behind the free joint's root chain (dofs 0..5) the dof tree splits into independent
 // branches (abdomen chain 14, head subtree 14, wings 3 + 3, halteres 1 + 1), so the leaf-to-root substitution runs all branches
 // at once: in step t every lane looks at the t-th pivot of ITS OWN branch (a byte of c.seq) and fetches that pivot's value
@@ -1082,7 +1178,7 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
       else { a = solve<0>(c, f); ae = a; }
     }
 #else
-    factor<true>(c, 0.f, hB);
+    bfactor<true>(c, 0.f, hB);
     if (want_euler) { const float2 r = bsolve<2>(c, f); a = r.x; ae = r.y; }
     else { a = bsolve<0>(c, f).x; ae = a; }
 #endif
@@ -1091,8 +1187,13 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
     for (int it = 0; it < 8; it++) {
       const float add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
       const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
+#ifdef FFE_OLD_SOLVE
       if (it == 0) factor<true>(c, add, hB);   // constraint Hessian and Euler matrix in one sweep
       else factor<false>(c, add, 0.f);          // active set changed: refactor the Hessian only
+#else
+      if (it == 0) bfactor<true>(c, add, hB);
+      else bfactor<false>(c, add, 0.f);
+#endif
 #ifdef FFE_OLD_SOLVE
       a = solve<0>(c, rhs);
 #else
