@@ -22,6 +22,7 @@ sys.path.insert(0, "/root/reference")
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 from vnl_ray import quaternions as RQ  # noqa: E402
+from vnl_ray.tasks import rewards as RR  # noqa: E402
 from vnl_ray.tasks.pattern_generators import WingBeatPatternGenerator  # noqa: E402
 
 from flybody_amd.tasks.synthetic import base_wing_pattern  # noqa: E402
@@ -114,7 +115,47 @@ def wbpg_goldens():
     print("wbpg.npz: rows", traj.shape[0], "switches", int((np.diff(fi) != 0).sum()))
 
 
+def rewards_goldens():
+    """vnl_ray.tasks.rewards (walking imitation): compute_diffs, reward_factors_deep_mimic and
+    get_reference_features on seeded features shaped like the fly's (108 dofs, 6 end-effector sites, root + 102 joint quaternions)."""
+    rng = np.random.RandomState(4321)
+    ncase, nv, nsite, nj = 12, 108, 6, 102
+    out = dict(ncase=np.array(ncase))
+
+    def unit(x):
+        return x / np.linalg.norm(x, axis=-1, keepdims=True)
+
+    T = 9
+    ref = dict(qpos=np.concatenate((rng.randn(T, 3) * 0.1, unit(rng.randn(T, 4)), rng.uniform(-1, 1, (T, nj))), axis=1),
+               qvel=rng.randn(T, nv) * 20.0, root2site=rng.randn(T, nsite, 3) * 0.1, joint_quat=unit(rng.randn(T, nj, 4)))
+    for k, v in ref.items():
+        out["ref_" + k] = v
+    for c in range(ncase):
+        step = c % T
+        rf = RR.get_reference_features(ref, step)
+        for k, v in rf.items():
+            out[f"reffeat{c}_{k}"] = np.asarray(v)
+        scale = [0.0, 1e-3, 1e-2, 0.05, 0.2, 1.0][c % 6]   # from identical to unrelated
+        wf = {
+            "com": rf["com"] + scale * rng.randn(3) * 0.1,
+            "qvel": rf["qvel"] + scale * rng.randn(nv) * 30.0,
+            "root2site": rf["root2site"] + scale * rng.randn(nsite, 3) * 0.1,
+            "joint_quat": unit(rf["joint_quat"] + scale * rng.randn(nj + 1, 4)) * (1.0 if c % 2 else rng.uniform(0.5, 2.0)),  # scale-invariant
+        }
+        for k, v in wf.items():
+            out[f"walker{c}_{k}"] = v
+        for n in (1, 2):
+            d = RR.compute_diffs(wf, rf, n=n)
+            out[f"diffs{c}_n{n}"] = np.array([d[k] for k in ("com", "qvel", "root2site", "joint_quat")])
+        out[f"factors{c}"] = RR.reward_factors_deep_mimic(wf, rf)
+        std = {"com": 0.05, "qvel": 30.0, "root2site": 0.1, "joint_quat": 0.8}
+        out[f"factors{c}_custom"] = RR.reward_factors_deep_mimic(wf, rf, std=std, weights=(1.0, 0.5, 2.0, 0.25))
+    np.savez_compressed(os.path.join(OUT, "rewards.npz"), **out)
+    print("rewards.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quaternion_goldens()
     wbpg_goldens()
+    rewards_goldens()
