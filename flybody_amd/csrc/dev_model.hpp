@@ -353,7 +353,8 @@ inline HostModel build_host_model(const Blob &b) {
     V.fs_branch_rounds = static_cast<int>(fsched.size() / kWave);
     for (int k = nroot - 1; k > 0; k--) emit_step({{k, -1}});
     V.fs_rounds = static_cast<int>(fsched.size() / kWave);
-    for (int l = 0; l < 2 * kWave; l++) fsched.push_back(0u);  // read-ahead padding
+    if (V.fs_rounds - V.fs_branch_rounds > 6) throw std::runtime_error("root chain longer than the kernel unrolls");
+    for (int l = 0; l < 10 * kWave; l++) fsched.push_back(0u);  // read-ahead padding
   }
   const int nM = static_cast<int>(m_row.size());
   if (nM > kMaxM) throw std::runtime_error("mass matrix exceeds kernel capacity");

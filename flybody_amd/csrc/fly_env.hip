@@ -984,13 +984,24 @@ __device__ __forceinline__ void bfactor(Ctx &c, float add0, float add1) {
         }
       }
     };
-    unsigned w = tab[0];
+    // schedule words travel a group of four rounds ahead of their use (an L2 round trip is longer than one round)
+    unsigned wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wq[q] = tab[q * kWave];
 #pragma unroll 1
-    for (int r = 0; r < nbr_rounds; r++) {
-      const unsigned wn = tab[(r + 1) * kWave];
-      round(w);
-      if (__builtin_amdgcn_readfirstlane(w) & 0x40000000u) SYNC();  // last round of a step: the next pivots read what this step wrote
-      w = wn;
+    for (int base = 0; base < nbr_rounds; base += 4) {
+      unsigned cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) cw[q] = wq[q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) wq[q] = tab[(base + 4 + q) * kWave];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (base + q < nbr_rounds) {  // wave-uniform
+          round(cw[q]);
+          if (__builtin_amdgcn_readfirstlane(cw[q]) & 0x40000000u) SYNC();  // last round of a step: the next pivots read what this step wrote
+        }
+      }
     }
     SYNC();
     // fold the branches' root-block copies into the root rows, then eliminate the root chain
@@ -1000,12 +1011,17 @@ __device__ __forceinline__ void bfactor(Ctx &c, float add0, float add1) {
       if (DUAL) T.LD[lane] = acc; else T.LD[lane].x = acc.x;
     }
     SYNC();
-#pragma unroll 1
-    for (int r = nbr_rounds; r < nrounds; r++) {
-      const unsigned wn = tab[(r + 1) * kWave];
-      round(w);
-      SYNC();
-      w = wn;
+    {  // root chain: nroot - 1 single-round steps
+      unsigned rw[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) rw[q] = tab[(nbr_rounds + q) * kWave];  // (issued before the fold above completes: independent)
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        if (nbr_rounds + q < nrounds) {
+          round(rw[q]);
+          SYNC();
+        }
+      }
     }
   }
   if (DUAL) {
