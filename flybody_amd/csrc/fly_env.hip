@@ -369,7 +369,7 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(k) do {} while (0)
 #endif
 // timing-only ablation switches (bench experiments; results are wrong when set)
-enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22, DBG_NO_CARRY = 1 << 23 };
+enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22, DBG_NO_CARRY = 1 << 23, DBG_NO_ORDER = 1 << 24 };
 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
@@ -1942,7 +1942,7 @@ static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, f
   if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
   // measured: +2 % env-steps/s at B = 8 192 (two rounds of the 4 096 resident waves); beyond that the tail the order shortens
   // is a smaller share of the launch than the serialised sort kernel itself (-1.5 % at 16 384, -2 % at 32 768): not sorted
-  if (mode == 0 && h->batch > 1 && h->batch <= 8192) {
+  if (mode == 0 && h->batch > 1 && h->batch <= 8192 && !(h->task.flags & DBG_NO_ORDER)) {
     hipLaunchKernelGGL(ffe_order::order_by_cost, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), h->cost, h->order, h->batch);
     e = hipGetLastError();
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }

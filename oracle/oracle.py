@@ -52,7 +52,7 @@ def lib():
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [vp]
         for n in ("fo_act", "fo_efc_force", "fo_efc_J", "fo_efc_aref", "fo_efc_D", "fo_sens_touch", "fo_sens_force",
-                  "fo_site_xpos", "fo_geom_xpos", "fo_qpos_spring"):
+                  "fo_site_xpos", "fo_geom_xpos", "fo_geom_xmat", "fo_qpos_spring"):
             getattr(L, n).restype = dp
             getattr(L, n).argtypes = [vp]
         L.fo_efc_type.restype = ip
@@ -182,6 +182,7 @@ class OracleData:
             self.sens_touch, self.sens_force = view("fo_sens_touch", m.ntouch), view("fo_sens_force", 3 * m.nforce).reshape(-1, 3)
             self.site_xpos = view("fo_site_xpos", 3 * m.nsite).reshape(-1, 3)
             self.geom_xpos = view("fo_geom_xpos", 3 * m.ngeom).reshape(-1, 3)
+            self.geom_xmat = view("fo_geom_xmat", 9 * m.ngeom).reshape(-1, 3, 3)
             self.efc_force = view("fo_efc_force", 300)
 
     @property

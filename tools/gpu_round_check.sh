@@ -1,13 +1,19 @@
+# Round-end evidence on the GPU box (run through gpurun): tests, smoke, benches, rocprofv3 kernel stats, PMC passes, stamps.
+#   gpurun --timeout 1200 -- 'bash tools/gpu_round_check.sh r02'
 set -o pipefail
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/$TAG
+O=$R/gpurun_out/$TAG
 cd $R
-timeout -k 10 400 python -m pytest tests -m gpu -q -s 2>&1 | grep -v amdgpu | tail -40 | cut -c1-600 > gpurun_out/r01b_gpu_tests.log; tail -25 gpurun_out/r01b_gpu_tests.log
-timeout -k 10 200 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu | tail -3 | tee gpurun_out/r01b_smoke.log
-timeout -k 10 300 python bench.py --workload walk_on_ball 2>&1 | grep -v amdgpu | tail -1 | tee gpurun_out/r01b_bench_walk_on_ball.log
-timeout -k 10 300 python bench.py 2>&1 | grep -v amdgpu | tail -1 | tee gpurun_out/r01b_bench_default_run.log
-FLYBODY_ENV_LIB=flybody_amd/csrc/variants/libflybody_env_bstamps.so timeout -k 10 200 python tools/ball_stamps.py 2>&1 | grep -v amdgpu > gpurun_out/r01b_ball_stamp_shares.log
+timeout -k 10 600 python -m pytest tests -m gpu -q -s 2>&1 | grep -v amdgpu | cut -c1-700 > $O/gpu_tests.log; tail -3 $O/gpu_tests.log
+timeout -k 10 200 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu | tail -3 | tee $O/smoke.log
+timeout -k 10 300 python bench.py --rehearse-gather 2>&1 | grep -v amdgpu | tail -1 | tee $O/bench_flight.log | cut -c1-200
+timeout -k 10 300 python bench.py --workload walk_on_ball 2>&1 | grep -v amdgpu | tail -1 | tee $O/bench_walk_on_ball.log | cut -c1-200
+FLYBODY_ENV_LIB=flybody_amd/csrc/variants/libflybody_env_bstamps.so timeout -k 10 200 python tools/ball_stamps.py 2>&1 | grep -v amdgpu > $O/ball_stamp_shares.log
+timeout -k 10 200 python tools/stamps.py 2>&1 | grep -v amdgpu > $O/flight_stamp_shares.log
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ball -o ball -- python3 $R/bench.py --workload walk_on_ball --no-cpu-baseline > $R/gpurun_out/r01b_rocprof_ball.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_flight -o flight -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/r01b_rocprof_flight.log 2>&1
-ls -R $R/gpurun_out/prof_ball $R/gpurun_out/prof_flight | head -20
-cd $R && bash tools/pmc_ball.sh > gpurun_out/r01b_pmc_ball.log 2>&1; tail -3 gpurun_out/r01b_pmc_ball.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ball -o ball -- python3 $R/bench.py --workload walk_on_ball --no-cpu-baseline > $O/rocprof_ball.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_flight -o flight -- python3 $R/bench.py --no-cpu-baseline > $O/rocprof_flight.log 2>&1
+cd $R && bash tools/pmc_ball.sh > $O/pmc_ball.log 2>&1; tail -2 $O/pmc_ball.log
+cd $R && bash tools/pmc_flight.sh > $O/pmc_flight.log 2>&1; tail -2 $O/pmc_flight.log
+cd $R && bash tools/batch_scaling.sh > $O/batch_scaling.log 2>&1; tail -3 $O/batch_scaling.log
