@@ -316,7 +316,7 @@ def main():
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("walk_on_ball (BASELINE configs[2]): 10 substeps @2e-4 s, ball contacts (elliptic cones, Newton + noslip), adhesion, "
+            "config": {"workload": ("walk_on_ball (BASELINE configs[2]): 10 substeps @2e-4 s, ball contacts (elliptic cones, Newton + noslip), fly-fly sphere/capsule contacts, adhesion, "
                                     "filtered actuators, touch/force sensors, obs/reward/termination/auto-reset") if ball else
                                    "flight_imitation (BASELINE configs[3]): 4 substeps @5e-5 s + WBPG + obs/reward/termination/auto-reset",
                        "envs_per_gpu": B, "global_batch": world * B, "parallelism": f"env-sharded x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
