@@ -9,6 +9,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libflybody_env.so")
 SOURCES = ["fly_env.hip", "ball_env.hip", "nstep.hip"]
+# Loop-invariant code motion hoists per-lane LDS addresses and literal constants out of the substep loop of the two step
+# kernels and then spills them.  flight: no machine LICM -> 119 VGPRs, 0 B scratch (was 56 B; +0.5 % env-steps/s);
+# walk_on_ball: sinking invariants back into the loop where that avoids a spill -> 176 B scratch (was 548 B; +1.2 %).  Measured
+# each way on both kernels (profiles/r02_compiler_flag_ab.log).
+PER_SOURCE_FLAGS = {
+    "fly_env.hip": ["-mllvm", "-disable-machine-licm"],
+    "ball_env.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
+}
 HEADERS = ["dev_model.hpp", "ball_model.hpp", "ball_env.hpp", "dev_math.hpp", "launch_order.hpp", os.path.join("..", "..", "include", "flybody_env.h")]
 
 
@@ -27,11 +35,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # v_pk_mul + moves, which costs more than it saves in both kernels (+3 % env-steps/s without it, measured).
     # iterative-ilp scheduling: the default scheduler serialises every v_readlane -> s_nop -> v_fma pair of the unrolled dense
     # loops through one SGPR; the ILP scheduler batches the broadcasts (walk_on_ball +8.6 %, flight +0.8 %, measured)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
-           "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
+              "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, "_obj_" + os.path.splitext(src)[0] + ".o")
+        cmd = common + PER_SOURCE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    for obj in objs:
+        os.remove(obj)
     return LIB
 
 

@@ -88,6 +88,8 @@ struct alignas(16) Tile {
   float sens[12];    // running sums of the buffered sensors: acc[3], gyro[3], vel[3]
   double rootpos[4];  // free-joint position in float64
   double ghost[16];   // pos[3], quat[4], vel[3], angvel[3]
+  double park_d[2];   // wave-uniform task values parked over the physics loop (see flight_step_kernel)
+  int park_i[8];
 };
 
 static_assert(offsetof(Tile, cdof) % 8 == 0 && offsetof(Tile, buf) % 8 == 0 && sizeof(float[6]) % 8 == 0, "ld6a needs 8-byte aligned 6-vector rows");
@@ -368,7 +370,22 @@ __device__ unsigned long long g_stamps[16];
 #else
 #define STAMP(k) do {} while (0)
 #endif
+// The whole-fly CoM (wave-uniform) lives in a spare corner of the LDS tile unless FFE_COM_REG pins it in three VGPRs.
+#ifdef FFE_COM_REG
+__device__ __forceinline__ void set_com(Ctx &c, V3 v) { c.com = v; }
+__device__ __forceinline__ V3 get_com(const Ctx &c) { return c.com; }
+#else
+__device__ __forceinline__ void set_com(Ctx &c, V3 v) { if (c.lane == 0) { c.T.sens[9] = v.x; c.T.sens[10] = v.y; c.T.sens[11] = v.z; } }
+__device__ __forceinline__ V3 get_com(const Ctx &c) { return {c.T.sens[9], c.T.sens[10], c.T.sens[11]}; }
+#endif
 // timing-only ablation switches (bench experiments; results are wrong when set)
+// The in-kernel ones exist only in the -DFFE_ABLATION diagnostic build (tools/ablate.py); the shipped kernel carries neither the
+// branches nor the flag bits through its loops.
+#ifdef FFE_ABLATION
+#define DBG(c, f) ((c).flags & (f))
+#else
+#define DBG(c, f) (0)
+#endif
 enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22, DBG_NO_CARRY = 1 << 23, DBG_NO_ORDER = 1 << 24 };
 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
@@ -455,13 +472,15 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     xo[0] = xm.m0; xo[1] = xm.m1; xo[2] = xm.m2; xo[3] = xm.m3; xo[4] = xm.m4; xo[5] = xm.m5; xo[6] = xm.m6; xo[7] = xm.m7; xo[8] = xm.m8;
   }
   // mj: mj_comPos - CoM of the whole tree (all lanes take part in the reduction)
+  V3 com1;
   {
     float inv = 1.0f / M.total_mass;
-    c.com = {wave_sum(mass * xip.x) * inv, wave_sum(mass * xip.y) * inv, wave_sum(mass * xip.z) * inv};
+    com1 = {wave_sum(mass * xip.x) * inv, wave_sum(mass * xip.y) * inv, wave_sum(mass * xip.z) * inv};
+    set_com(c, com1);
   }
   I10 cin = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (is_link) {
-    cin = inert_com(ldv_lane(M.l_inertia, lane), xim, xip - c.com, mass);
+    cin = inert_com(ldv_lane(M.l_inertia, lane), xim, xip - com1, mass);
     st10(T.cinert[lane], cin);
   }
   SYNC();
@@ -482,7 +501,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
         V3 b = {T.cdof[lane][0], T.cdof[lane][1], T.cdof[lane][2]};
         ax = mv(ldm(xo), b);
       }
-      V3 off = c.com - V3{T.xpos[d_link][0], T.xpos[d_link][1], T.xpos[d_link][2]};
+      V3 off = get_com(c) - V3{T.xpos[d_link][0], T.xpos[d_link][1], T.xpos[d_link][2]};
       cd = mk6(ax, cross(ax, off));
     }
   }
@@ -552,7 +571,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     const V3 xp2 = {T.xpos[ll][0], T.xpos[ll][1], T.xpos[ll][2]};
     const M3 xm2 = ldm(T.xmat[ll]);
     const S6 cvel3 = ld6(T.lb[ll]);
-    const V3 off = xp2 - c.com;
+    const V3 off = xp2 - get_com(c);
     const V3 w_w = ang(cvel3);
     const V3 w_b = mtv(xm2, w_w), v_b = mtv(xm2, lin(cvel3) + cross(w_w, off));
     S6 wl = zero6();
@@ -653,7 +672,7 @@ __device__ __forceinline__ void factor(Ctx &c, float add0, float add1) {
       const int e = lane + r * kWave;
       if (e < M.nM) {
         float m = dot6(ld6a(T.cdof[ej[r]]), ld6a(T.buf[ei[r]]));
-        if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + ((c.flags & DBG_SKIP_MENTRIES) ? 1.f : 0.f);
+        if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + (DBG(c, DBG_SKIP_MENTRIES) ? 1.f : 0.f);
         if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
       }
     }
@@ -665,7 +684,7 @@ __device__ __forceinline__ void factor(Ctx &c, float add0, float add1) {
   }
   SYNC();
   STAMP(4);  // M entries
-  if (c.flags & DBG_SKIP_FACTOR) {
+  if (DBG(c, DBG_SKIP_FACTOR)) {
     c.dinv[0] = lane < nv ? 1.0f / T.LD[d_madr].x : 0.f;
     if (DUAL) c.dinv[1] = lane < nv ? 1.0f / T.LD[d_madr].y : 0.f;
     return;
@@ -721,7 +740,7 @@ __device__ __forceinline__ float solve(Ctx &c, float rhs) {
   const bool is_dof = lane < nv;
   const float dinv = c.dinv[COMP];
   const float *LDc = reinterpret_cast<const float *>(T.LD) + COMP;  // entry e of this factor sits at LDc[2 e]
-  if (c.flags & DBG_SKIP_SOLVE) return is_dof ? rhs * dinv : 0.f;
+  if (DBG(c, DBG_SKIP_SOLVE)) return is_dof ? rhs * dinv : 0.f;
   STAMP(6);  // stage-2 glue before a solve
   float x = is_dof ? rhs : 0.f;
   const int my_end = lane + d_ndesc;         // last descendant dof of this lane
@@ -879,7 +898,7 @@ __device__ __forceinline__ float2 solve_both(Ctx &c, float rhs) {
   const bool is_dof = lane < nv;
   const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
   const float di0 = c.dinv[0], di1 = c.dinv[1];
-  if (c.flags & DBG_SKIP_SOLVE) return is_dof ? make_float2(rhs * di0, rhs * di1) : make_float2(0.f, 0.f);
+  if (DBG(c, DBG_SKIP_SOLVE)) return is_dof ? make_float2(rhs * di0, rhs * di1) : make_float2(0.f, 0.f);
   STAMP(6);
   float x0 = is_dof ? rhs : 0.f, x1 = x0;
   const int my_end = lane + d_ndesc, my_md = d_madr + d_depth, dep = d_depth;
@@ -951,7 +970,7 @@ __device__ __forceinline__ void bfactor(Ctx &c, float add0, float add1) {
       const int e = lane + r * kWave;
       if (e < M.nM) {
         float m = dot6(ld6a(T.cdof[ej[r]]), ld6a(T.buf[ei[r]]));
-        if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + ((c.flags & DBG_SKIP_MENTRIES) ? 1.f : 0.f);
+        if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + (DBG(c, DBG_SKIP_MENTRIES) ? 1.f : 0.f);
         if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
       }
     }
@@ -966,7 +985,7 @@ __device__ __forceinline__ void bfactor(Ctx &c, float add0, float add1) {
   }
   SYNC();
   STAMP(4);  // M entries
-  if (!(c.flags & DBG_SKIP_FACTOR)) {
+  if (!DBG(c, DBG_SKIP_FACTOR)) {
     const unsigned FFE_GLOBAL *tab = M.fsched + lane;
     const int nbr_rounds = M.fs_branch_rounds, nrounds = M.fs_rounds;
     auto round = [&](unsigned w) {
@@ -1059,7 +1078,7 @@ __device__ __forceinline__ float2 bsolve(Ctx &c, float rhs) {
     const float *p = reinterpret_cast<const float *>(T.LD) + 2 * e;
     return MODE == 0 ? make_float2(p[0], 0.f) : make_float2(0.f, p[1]);
   };
-  if (c.flags & DBG_SKIP_SOLVE) return is_dof ? make_float2(rhs * di0, rhs * di1) : z2;
+  if (DBG(c, DBG_SKIP_SOLVE)) return is_dof ? make_float2(rhs * di0, rhs * di1) : z2;
   STAMP(6);
   float x0 = is_dof ? rhs : 0.f, x1 = x0;
   // ---- x <- L^-T x, branches: step t eliminates the t-th pivot of every branch
@@ -1144,6 +1163,11 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
+#ifndef FFE_SEQ_PINNED
+  // the factor / solve index words are stage-2 business only: re-read here, they are not carried through stage 1
+  c.la_pack = (unsigned)M.d_madr[lane] | ((unsigned)M.d_depth[lane] << 10) | ((unsigned)M.d_ndesc[lane] << 16);
+  c.seq0 = M.br_seq[lane]; c.seq1 = M.br_seq[kWave + lane]; c.seq2 = M.br_seq[2 * kWave + lane]; c.seq3 = M.br_seq[3 * kWave + lane];
+#endif
   const bool is_dof = lane < M.nv;
   const int d_kind = M.d_kind[lane];
   const float h = M.h;
@@ -1187,7 +1211,7 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   if (ex_any == 0ULL) {
     // no limit instantiated: one dual factorisation, one dual solve
 #ifdef FFE_OLD_SOLVE
-    if (want_euler && !(c.flags & (DBG_SKIP_FACTOR | DBG_SKIP_SOLVE))) { const float2 r = factor_solve_both(c, hB, f); a = r.x; ae = r.y; }
+    if (want_euler && !DBG(c, DBG_SKIP_FACTOR | DBG_SKIP_SOLVE)) { const float2 r = factor_solve_both(c, hB, f); a = r.x; ae = r.y; }
     else {
       factor<true>(c, 0.f, hB);
       if (want_euler) { const float2 r = solve_both(c, f); a = r.x; ae = r.y; }
@@ -1521,7 +1545,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
       wb_step = (wb_step + 1) % len;
       wb_cf = wbpg_filter(wb_cf, K.rate, K.base_freq, K.rel_range, (double)act_user);
-      int idx_new = (c.flags & DBG_SKIP_WBPG) ? wb_idx
+      int idx_new = DBG(c, DBG_SKIP_WBPG) ? wb_idx
                     : (K.grid_inv_step > 0.0 ? grid_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, K.grid_inv_step)
                                              : wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane));
       if (idx_new != wb_idx) {
@@ -1555,9 +1579,21 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   // ---- physics.  dm_control's legacy step is mj_step2 then mj_step1, so the position/velocity stage is evaluated
   //      once up front and again after every integration; buffered sensors take one sample per substep.  A reset
   //      is the same pipeline run once without actuation and without integrating (mj_forward).
-  const float abase = do_reset ? 0.f : actuation_base(c, ctrl_reg);
+  {
+    // per-lane, fixed over the control step: kept in the (now dead) control staging slots rather than in a register
+    const float abase = do_reset ? 0.f : actuation_base(c, ctrl_reg);
+    if (lane < kMaxAct) T.ctrl[lane] = abase;
+  }
+#ifndef FFE_NO_PARK
+  // the task's wave-uniform values are not needed before the epilogue: parked in LDS, they do not sit in (or spill from)
+  // vector registers through the physics loop
+  if (lane == 0) {
+    T.park_d[0] = wb_cf; T.park_d[1] = __longlong_as_double((long long)episode);
+    T.park_i[0] = wb_step; T.park_i[1] = wb_idx; T.park_i[2] = step_counter; T.park_i[3] = traj_idx; T.park_i[4] = 0;
+  }
+#endif
   STAMP(11);  // prologue: state load, WBPG, action mixing (or episode reset)
-  const bool have_saved = !do_reset && S.s1_valid != 0 && !(c.flags & DBG_NO_CARRY);
+  const bool have_saved = !do_reset && S.s1_valid != 0 && !DBG(c, DBG_NO_CARRY);
   const int nst = do_reset ? 1 : nsub;
 #pragma unroll 1
   for (int s = 0; s <= nst; s++) {
@@ -1565,9 +1601,9 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       for (int e = lane; e < kMaxDof * 6; e += kWave) { (&T.cdof[0][0])[e] = S.s1_cdof[e]; (&T.buf[0][0])[e] = S.s1_buf[e]; }
       c.f_smooth_nb = S.s1_f[lane];
       if (lane < 9) T.xmat[0][lane] = S.s1_misc[lane];
-      c.com = {S.s1_misc[9], S.s1_misc[10], S.s1_misc[11]};
+      set_com(c, V3{S.s1_misc[9], S.s1_misc[10], S.s1_misc[11]});
       SYNC();
-    } else if (!(c.flags & DBG_SKIP_STAGE1) || s == 0) stage1(c);
+    } else if (!DBG(c, DBG_SKIP_STAGE1) || s == 0) stage1(c);
     if (lane < 6 && (do_reset || s > 0)) {
       // buffered velocity sensors at the thorax site: gyro = body-frame angular velocity, velocimeter = R^T v
       float add;
@@ -1577,22 +1613,30 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     }
     if (s == nst) break;
     float qa = 0.f;
-    if (!do_reset) qa = actuation(c, abase);
+    if (!do_reset) qa = actuation(c, lane < kMaxAct ? T.ctrl[lane] : 0.f);
     STAMP(12);  // sensor accumulation + actuation
     int it = 0;
-    const V3 acc = stage2(c, qa, !do_reset, !do_reset && !phys_only && !(c.flags & DBG_SKIP_GHOST), K.ghost_accel_z, lo_mask, hi_mask, it);
+    const V3 acc = stage2(c, qa, !do_reset, !do_reset && !phys_only && !DBG(c, DBG_SKIP_GHOST), K.ghost_accel_z, lo_mask, hi_mask, it);
+#ifndef FFE_NO_PARK
+    if (lane == 0) T.park_i[4] += it;
+#else
     iters += it;
+#endif
     if (lane < 3) T.sens[lane] += lane == 0 ? acc.x : (lane == 1 ? acc.y : acc.z);
     if (do_reset) break;
   }
   SYNC();
+#ifndef FFE_NO_PARK
+  wb_cf = T.park_d[0]; episode = (unsigned long long)__double_as_longlong(T.park_d[1]);
+  wb_step = T.park_i[0]; wb_idx = T.park_i[1]; step_counter = T.park_i[2]; traj_idx = T.park_i[3]; iters = T.park_i[4];
+#endif
   V3 s_acc = {T.sens[0], T.sens[1], T.sens[2]}, s_gyro = {T.sens[3], T.sens[4], T.sens[5]}, s_vel = {T.sens[6], T.sens[7], T.sens[8]};
   if (!phys_only) {
   const float inv = (do_reset && K.pad_first_obs) ? 1.f : 1.f / (float)nsub;
   float cdist;
   Q4 rq0;
   const int traj_row0 = K.traj_off[traj_idx], traj_rows = K.traj_off[traj_idx + 1] - traj_row0;
-  if (c.flags & DBG_SKIP_OBS) { cdist = 0.f; rq0 = {1.f, 0.f, 0.f, 0.f}; }
+  if (DBG(c, DBG_SKIP_OBS)) { cdist = 0.f; rq0 = {1.f, 0.f, 0.f, 0.f}; }
   else write_obs(c, K, obs, inv * s_acc, inv * s_gyro, inv * s_vel, traj_row0, step_counter, cdist, rq0);
   if (do_reset) {
     if (lane == 0) { reward_out[env] = 0.f; discount_out[env] = 1.f; step_type_out[env] = FFE_STEP_FIRST; S.needs_reset = 0; S.forced_traj = -1; }
@@ -1610,12 +1654,13 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     if (lane == 0) {
       const double ox = -0.03697732, oy = 0.00029205, oz = -0.0142447;  // ref: task_utils.py:188
       const double *gpos = T.ghost, *rootpos = T.rootpos;
+      const V3 com_e = get_com(c);
       double w = T.ghost[3], x = T.ghost[4], y = T.ghost[5], z = T.ghost[6];
       double n2 = w * w + x * x + y * y + z * z;
       double gx = gpos[0] + ((w * w + x * x - y * y - z * z) * ox + 2 * (x * y - w * z) * oy + 2 * (x * z + w * y) * oz) / n2;
       double gy = gpos[1] + (2 * (x * y + w * z) * ox + (w * w - x * x + y * y - z * z) * oy + 2 * (y * z - w * x) * oz) / n2;
       double gz = gpos[2] + (2 * (x * z - w * y) * ox + 2 * (y * z + w * x) * oy + (w * w - x * x - y * y + z * z) * oz) / n2;
-      double dx = gx - (rootpos[0] + (double)c.com.x), dy = gy - (rootpos[1] + (double)c.com.y), dz = gz - (rootpos[2] + (double)c.com.z);
+      double dx = gx - (rootpos[0] + (double)com_e.x), dy = gy - (rootpos[1] + (double)com_e.y), dz = gz - (rootpos[2] + (double)com_e.z);
       float r1 = fmaxf(0.f, 1.f - (float)sqrt(dx * dx + dy * dy + dz * dz) / 0.4f);
       float r2 = fmaxf(0.f, 1.f - quat_dist_short_arc(Q4{1.f, 0.f, 0.f, 0.f}, rq0) / 3.14159265358979f);
       float reward = r1 * r2;
@@ -1646,7 +1691,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   for (int e = lane; e < kMaxDof * 6; e += kWave) { S.s1_cdof[e] = (&T.cdof[0][0])[e]; S.s1_buf[e] = (&T.buf[0][0])[e]; }
   S.s1_f[lane] = c.f_smooth_nb;
   if (lane < 9) S.s1_misc[lane] = T.xmat[0][lane];
-  if (lane == 0) { S.s1_misc[9] = c.com.x; S.s1_misc[10] = c.com.y; S.s1_misc[11] = c.com.z; S.s1_valid = 1; }
+  if (lane == 0) { const V3 com_e = get_com(c); S.s1_misc[9] = com_e.x; S.s1_misc[10] = com_e.y; S.s1_misc[11] = com_e.z; S.s1_valid = 1; }
 #ifdef FFE_STAMPS
   STAMP(10);
   if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);

@@ -1,5 +1,7 @@
-"""Timing-only ablations of the step kernel (results are wrong under the DBG flags; for profiling)."""
+"""Timing-only ablations of the step kernel (results are wrong under the DBG flags; for profiling).
+The in-kernel ablation switches exist only in the diagnostic build: bash tools/build_variants.sh first."""
 import sys, os
+os.environ.setdefault("FLYBODY_ENV_LIB", os.path.join(os.path.dirname(__file__), "..", "flybody_amd", "csrc", "variants", "libflybody_env_ablation.so"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from flybody_amd.batched_env import BatchedFlyEnv
