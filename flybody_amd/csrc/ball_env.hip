@@ -43,6 +43,10 @@ __device__ unsigned long long g_bstamps[24];
 #else
 #define BSTAMP(k) do { } while (0)
 #endif
+// Diagnostic build only (-DFFE_TRACE): start / end shader clock and hardware slot of every wave of the last launch (tools/wave_timeline.py)
+#ifdef FFE_TRACE
+__device__ unsigned long long g_btrace[32768][4];
+#endif
 constexpr int kMaxNewton = 12;
 constexpr float kNewtonTol2 = 1e-8f;  // stop when |grad| <= 1e-4 |force scale| (M^-1 metric; 1e-7 costs 4x in parity for 1% speed)
 constexpr int kLsIter = 10;
@@ -1584,6 +1588,9 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   // expensive ones (more contacts, more Newton iterations) start first and the launch does not end on a few long waves
   // running alone at low occupancy (launch_order.hpp; walk_on_ball, B = 4 096: -3 % launch time).
   if ((int)blockIdx.x >= batch) return;
+#ifdef FFE_TRACE
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int env = order[blockIdx.x], lane = threadIdx.x;
   if (mode == 3) {  // ffe_reset_envs: only the masked envs start a new episode; the others keep state and output rows
     if (!reset_mask[env]) return;
@@ -1733,6 +1740,13 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
       S.needs_reset = (bad || timeup) ? 1 : 0;
     }
   }
+#ifdef FFE_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0 && blockIdx.x < 32768) {
+    g_btrace[blockIdx.x][0] = tr_t0; g_btrace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    g_btrace[blockIdx.x][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_btrace[blockIdx.x][3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
 }
 
 __global__ void ball_init_states(BState *states, int *order, int *cost, int batch) {
@@ -1868,6 +1882,11 @@ void ball_get_task_state(BallEnv *e, int32_t *ints, double *reals, void *stream)
   hipLaunchKernelGGL(ball_task_state_kernel, dim3((e->batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->states, ints, reals, e->batch);
   HIPB_OK(hipGetLastError());
 }
+#ifdef FFE_TRACE
+extern "C" int ffb_debug_read_trace(unsigned long long *out, int nrows) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_btrace), (size_t)nrows * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FFB_STAMPS
 extern "C" int ffb_debug_read_stamps(unsigned long long *out24, int reset) {
   if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_bstamps), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;

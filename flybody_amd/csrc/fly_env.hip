@@ -44,7 +44,9 @@ struct alignas(64) EnvState {
   // Position/velocity-stage results of the state above (dof axes, crb*axes, smooth joint forces, root frame, CoM): the
   // last stage-1 evaluation of a control step is exactly the first one of the next, so it is carried over instead of
   // being recomputed (bit-identical by construction; dropped whenever the state is written from outside).
-  int s1_valid, pad_[15];
+  int s1_valid, pad_[3];
+  unsigned long long in_lo_mask, in_hi_mask;  // limits instantiated but resolved inactive by the last substep's solve (first guess of the next)
+  unsigned char cost_hist[32];  // solver iterations of the last control step that ended in each of 32 wing-beat phase bins (launch order)
   float s1_cdof[kMaxDof * 6], s1_buf[kMaxDof * 6], s1_f[kLanePad], s1_misc[16];
 };
 
@@ -372,6 +374,24 @@ __device__ unsigned long long g_stamps[16];
 // The whole-fly CoM (wave-uniform; stage 1 -> reward) lives in a spare corner of the LDS tile, not in three VGPRs.
 __device__ __forceinline__ void set_com(Ctx &c, V3 v) { if (c.lane == 0) { c.T.sens[9] = v.x; c.T.sens[10] = v.y; c.T.sens[11] = v.z; } }
 __device__ __forceinline__ V3 get_com(const Ctx &c) { return {c.T.sens[9], c.T.sens[10], c.T.sens[11]}; }
+// Diagnostic build only (-DFFE_TRACE): start / end shader clock and hardware slot of every wave of the last launch, for the
+// occupancy timeline of tools/wave_timeline.py (dispatch ramp, wave lifetimes, tail).
+#ifdef FFE_TRACE
+__device__ unsigned long long g_trace[32768][4];
+#define TRACE_BEGIN unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(); const int tr_prev = cost[order[blockIdx.x]]
+#define TRACE_END(slot, tr_extra)                                                                                              \
+  do {                                                                                                                         \
+    __builtin_amdgcn_s_waitcnt(0);                                                                                             \
+    if (threadIdx.x == 0 && (slot) < 32768) {                                                                                  \
+      g_trace[slot][0] = tr_t0; g_trace[slot][1] = __builtin_amdgcn_s_memrealtime();                                               \
+      g_trace[slot][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_ID */                                               \
+      g_trace[slot][3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) | ((unsigned long long)(tr_extra) << 8); /* XCC_ID | extra */ \
+    }                                                                                                                          \
+  } while (0)
+#else
+#define TRACE_BEGIN do {} while (0)
+#define TRACE_END(slot, tr_extra) do {} while (0)
+#endif
 // timing-only ablation switches (bench experiments; results are wrong when set)
 // The in-kernel ones exist only in the -DFFE_ABLATION diagnostic build (tools/ablate.py); the shipped kernel carries neither the
 // branches nor the flag bits through its loops.
@@ -1153,7 +1173,7 @@ __device__ __forceinline__ float2 bsolve(Ctx &c, float rhs) {
 // Stage 2 = mj_fwdActuation, mj_fwdAcceleration, mj_fwdConstraint (joint limits), accelerometer, mj_Euler.
 // `ctrl_force` is the per-dof generalized actuator force, already assembled.
 __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, bool with_ghost, double ghost_accel_z, unsigned long long &lo_mask,
-                     unsigned long long &hi_mask, int &iters_out) {
+                     unsigned long long &hi_mask, unsigned long long &in_lo, unsigned long long &in_hi, int &iters_out) {
   const DevModel FFE_CONST &M = model(c);
   Tile &T = c.T;
   const int lane = c.lane;
@@ -1195,7 +1215,10 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   // is M + diag(D_active), i.e. the same sparse factorisation with a different diagonal; with no limit instantiated it
   // degenerates to qacc = M^-1 qfrc_smooth.  The implicit-damping Euler solve (M + h B) reuses the same code as a final
   // pass of the loop so that factor/solve are instantiated once.
-  bool act_lo = ex_lo, act_hi = ex_hi;  // first guess: an instantiated limit is active
+  // first guess: an instantiated limit is active, unless the previous substep's solve found it instantiated but inactive (a
+  // joint beyond its range that is already being driven back stays in that state for several substeps: without the memory
+  // every one of them costs a second factorisation + solve)
+  bool act_lo = ex_lo && !((in_lo >> lane) & 1ULL), act_hi = ex_hi && !((in_hi >> lane) & 1ULL);
   float a = 0.f, ae = 0.f, fc = 0.f;
   int iters = 0;
   const bool want_euler = integrate && !(c.flags & FFE_NO_DAMPER);
@@ -1249,6 +1272,8 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   STAMP(14);  // (remaining glue inside the constraint/Euler block)
   lo_mask = __ballot(act_lo);
   hi_mask = __ballot(act_hi);
+  in_lo = __ballot(ex_lo && !act_lo);
+  in_hi = __ballot(ex_hi && !act_hi);
   iters_out = ex_any ? iters : 0;
   c.qacc = a;
   // ---- accelerometer (mj: mj_rnePostConstraint + mj_objectAcceleration at the thorax site, which sits at the
@@ -1450,6 +1475,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   const DevModel FFE_CONST &M = *Mp;
   const TaskDev FFE_CONST &K = *Kp;
   if ((int)blockIdx.x >= batch) return;
+  TRACE_BEGIN;
   const int env = order[blockIdx.x];  // most expensive envs first (launch_order.hpp)
   if (mode == 3) {  // ffe_reset_envs: only the masked envs start a new episode; the others keep state and output rows
     if (!reset_mask[env]) return;
@@ -1469,7 +1495,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
 
   if (lane < 3) T.rootpos[lane] = S.rootpos[lane];
   if (lane < 9) T.sens[lane] = 0.f;
-  unsigned long long lo_mask = S.lo_mask, hi_mask = S.hi_mask;
+  unsigned long long lo_mask = S.lo_mask, hi_mask = S.hi_mask, in_lo = S.in_lo_mask, in_hi = S.in_hi_mask;
   int wb_step = S.wb_step, wb_idx = S.wb_freq_idx, step_counter = S.step_counter, traj_idx = S.traj_idx;
   double wb_cf = S.wb_ctrl_freq;
   const bool do_reset = !phys_only && ((mode == 1) || (S.needs_reset != 0));
@@ -1523,7 +1549,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       T.qpos[M.wing_qadr[lane]] = q0;
       T.qvel[M.wing_dof[lane]] = (float)(((double)q1 - (double)q0) / K.dt_ctrl);
     }
-    lo_mask = hi_mask = 0ULL;
+    lo_mask = hi_mask = in_lo = in_hi = 0ULL;
     SYNC();
   } else if (phys_only) {
     if (lane < kMaxDof + 4) { T.qpos[lane] = S.qpos[lane]; T.qvel[lane] = S.qvel[lane]; }
@@ -1561,6 +1587,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
         wb_idx = idx_new;
       }
     }
+    STAMP(15);  // prologue up to the WBPG step
     if (lane < M.nu) {
       int ai = M.a_action[lane];
       T.ctrl[lane] = ai >= 0 ? read_action(ai) : 0.f;
@@ -1623,7 +1650,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     if (!do_reset) qa = actuation(c, lane < kMaxAct ? T.ctrl[lane] : 0.f);
     STAMP(12);  // sensor accumulation + actuation
     int it = 0;
-    const V3 acc = stage2(c, qa, !do_reset, !do_reset && !phys_only && !DBG(c, DBG_SKIP_GHOST), K.ghost_accel_z, lo_mask, hi_mask, it);
+    const V3 acc = stage2(c, qa, !do_reset, !do_reset && !phys_only && !DBG(c, DBG_SKIP_GHOST), K.ghost_accel_z, lo_mask, hi_mask, in_lo, in_hi, it);
     if (lane == 0) T.park_i[4] += it;
     if (lane < 3) T.sens[lane] += lane == 0 ? acc.x : (lane == 1 ? acc.y : acc.z);
     if (do_reset) break;
@@ -1682,11 +1709,22 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   if (lane == 0) {
     S.rootpos[0] = T.rootpos[0]; S.rootpos[1] = T.rootpos[1]; S.rootpos[2] = T.rootpos[2];
     S.wb_ctrl_freq = wb_cf; S.wb_step = wb_step; S.wb_freq_idx = wb_idx; S.step_counter = step_counter; S.traj_idx = traj_idx;
-    S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.solver_iters = iters;
+    S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.in_lo_mask = in_lo; S.in_hi_mask = in_hi; S.solver_iters = iters;
     S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
-    // key of the next launch's order: constraint-solver iterations of this step (0 while no joint limit is active), then the
-    // number of active limits
-    cost[env] = 8 * iters + min(7, S.nactive);
+    // Key of the next launch's order = the solver work the next step is expected to need.  Joint limits are hit at fixed
+    // phases of the wing beat (stroke reversal), so the work is periodic in the WBPG phase: besides this step's own iterations
+    // the key takes the iterations recorded, one beat earlier, in the phase bins the next step will fall into (misses of
+    // heavy steps on the bench workload: 21 % with the last step alone, 1.3 % with both; tools/cost_history.py).
+    int pred = iters;
+    if (!phys_only) {
+      const int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
+      const int b = min(31, (int)(K.phase_frac[off + wb_step] * 32.0));
+      const int nb = min(31, (int)(K.phase_frac[off + (wb_step + 1 < len ? wb_step + 1 : 0)] * 32.0));
+      if (do_reset) { for (int k = 0; k < 32; k++) S.cost_hist[k] = 0; }
+      else S.cost_hist[b] = (unsigned char)min(iters, 255);
+      pred = max(pred, max((int)S.cost_hist[nb], (int)S.cost_hist[(nb + 1) & 31]));
+    }
+    cost[env] = 8 * pred + min(7, S.nactive);
   }
   // carry the final stage-1 results to the next launch (a reset's single evaluation is that of the FIRST state)
   for (int e = lane; e < kMaxDof * 6; e += kWave) { S.s1_cdof[e] = (&T.cdof[0][0])[e]; S.s1_buf[e] = (&T.buf[0][0])[e]; }
@@ -1697,6 +1735,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   STAMP(10);
   if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);
 #endif
+  TRACE_END(blockIdx.x, (unsigned)(iters & 0xff) | ((unsigned)(__popcll(lo_mask) + __popcll(hi_mask)) << 8) | ((unsigned)(tr_prev & 0xffff) << 16));  // this step's solver iterations, active limits at its end, the sort key it was launched with
 }
 
 __global__ void init_states_kernel(EnvState *states, int *order, int *cost, int batch) {
@@ -1723,7 +1762,7 @@ __global__ void set_state_kernel(EnvState *states, const double *qpos, const dou
   EnvState &S = states[env];
   if (lane < nq) { if (lane < 3) S.rootpos[lane] = qpos[(size_t)env * nq + lane]; else S.qpos[lane] = (float)qpos[(size_t)env * nq + lane]; }
   if (lane < nv) S.qvel[lane] = (float)qvel[(size_t)env * nv + lane];
-  if (lane == 0) { S.lo_mask = 0; S.hi_mask = 0; S.s1_valid = 0; }
+  if (lane == 0) { S.lo_mask = 0; S.hi_mask = 0; S.in_lo_mask = 0; S.in_hi_mask = 0; S.s1_valid = 0; }
 }
 __global__ void get_task_state_kernel(const EnvState *states, int *ints, double *reals, int batch) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2080,6 +2119,14 @@ int ffe_time_steps(ffe_handle h, const float *act, float *obs, float *rew, float
 int ffe_debug_read_stamps(unsigned long long *out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+
+#ifdef FFE_TRACE
+// rows of {start clock, end clock, HW_ID, XCC_ID} per workgroup of the last flight launch (walk_on_ball: ffb_debug_read_trace)
+int ffe_debug_read_trace(unsigned long long *out, int nrows) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)nrows * 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
   return 0;
 }
 #endif

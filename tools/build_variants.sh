@@ -19,4 +19,5 @@ variant() {  # name, extra macro flags
 variant stamps -DFFE_STAMPS
 variant bstamps -DFFB_STAMPS
 variant ablation -DFFE_ABLATION
+variant trace -DFFE_TRACE
 ls -la $C/variants

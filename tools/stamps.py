@@ -10,7 +10,7 @@ from flybody_amd.tasks.trajectories import preprocess
 from flybody_amd.tasks.wbpg import build_tables
 
 NAMES = ["s1 kinematics+com+cinert", "s1 cdof+velocities", "s1 rne fwd+fluid", "s1 subtree sums+joint space", "factor: M entries", "factor: elimination",
-         "stage2 glue (limits, actuation)", "triangular solves", "integration+sensors+ghost+prologue", "epilogue obs/reward", "store", "prologue (load, WBPG, action mix)", "sensor accumulation + actuation", "limit instantiation", "constraint block tail", "-"]
+         "stage2 glue (limits, actuation)", "triangular solves", "integration+sensors+ghost+prologue", "epilogue obs/reward", "store", "prologue: action mix, wing targets, ghost, actuator base", "sensor accumulation + actuation", "limit instantiation", "constraint block tail", "prologue: launch, state load, WBPG step"]
 tables = build_tables(base_wing_pattern()); rq, rv = preprocess(*flight_trajectories(64, 3006))
 B = 8192
 env = BatchedFlyEnv(tables, rq, rv, batch_size=B, seed=0)
