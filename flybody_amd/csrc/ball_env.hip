@@ -1590,6 +1590,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   if ((int)blockIdx.x >= batch) return;
 #ifdef FFE_TRACE
   const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+  const int tr_prev = cost[order[blockIdx.x]];
 #endif
   const int env = order[blockIdx.x], lane = threadIdx.x;
   if (mode == 3) {  // ffe_reset_envs: only the masked envs start a new episode; the others keep state and output rows
@@ -1682,7 +1683,9 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
     S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc + c.nsc; S.nself = c.nsc;
     S.con_hist[0] = (unsigned)con_hist; S.con_hist[1] = (unsigned)(con_hist >> 32);
-    cost[env] = iters;  // key of the next launch's order: Newton iterations over this step's substeps, what the launch time varies with
+    // key of the next launch's order: what a wave's lifetime varies with - Newton iterations over the step's substeps (4 us each)
+    // and the number of contacts (40 us each; least-squares fit of the lifetimes in tools/wave_timeline.py's trace)
+    cost[env] = min(255, iters + 10 * (c.nc + c.nsc));
     if (do_reset) S.overflow = 0; else if (c.overflow) S.overflow = 1;
     S.have_ws = do_reset ? 0 : c.have_ws;
   }
@@ -1744,7 +1747,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
   __builtin_amdgcn_s_waitcnt(0);
   if (lane == 0 && blockIdx.x < 32768) {
     g_btrace[blockIdx.x][0] = tr_t0; g_btrace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-    g_btrace[blockIdx.x][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_btrace[blockIdx.x][3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    g_btrace[blockIdx.x][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_btrace[blockIdx.x][3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) | ((unsigned long long)((unsigned)(iters & 0xff) | ((unsigned)((c.nc + c.nsc) & 0xff) << 8) | ((unsigned)(tr_prev & 0xffff) << 16)) << 8);
   }
 #endif
 }
