@@ -60,8 +60,15 @@ def walk_on_ball(random_state=None, *, batch_size: int = 1, device: int = 0, **e
     return BatchedBallEnv(batch_size=batch_size, device=device, time_limit=2.0, **env_kwargs)
 
 
-def walk_imitation(*args, **kwargs):
-    raise NotImplementedError("walk_imitation is a 'next' row of SURVEY.md section 8(f); not built yet")
+def walk_imitation(ref_path=None, random_state=None, terminal_com_dist: float = 0.3, **env_kwargs):
+    """Requires a fruitfly to track a reference walking fly (`fly_envs.py:75-122`).
+
+    Built so far: the compiled model (`assets/fly_walk.ffmb`: free root, floor plane, Walking
+    configuration), the snippet layout and walker features (`tasks/walking.py`), the DeepMimic reward maths (`tasks/rewards.py`)
+    and the float64 CPU restatement of the whole task that the tests check against (test infrastructure, outside this package).  The free-root contact step kernel is
+    not written yet, and this package has no CPU path: the factory fails instead of returning a slow environment."""
+    raise NotImplementedError("walk_imitation: model, reference layout, reward maths and oracle exist; the HIP step kernel "
+                              "(free root + floor contacts) is not built yet - see DESIGN.md section 2 row f3")
 
 
 def vision_guided_flight(*args, **kwargs):

@@ -915,8 +915,9 @@ def compile_model(doc: Document, mesh_dir: str, fallback_mesh_dir: str, timestep
     # ---- collision geoms, contact excludes, weld ids ------------------------------------------------------
     GEOM_CODE = {"plane": 0, "hfield": 1, "sphere": 2, "capsule": 3, "ellipsoid": 4, "cylinder": 5, "box": 6, "mesh": 7}
     gb, gt, gs, gp, gq, gcd, gfr, gma, gga, gsr, gsi, gmx, gpr, gct, gca = ([] for _ in range(15))
-    for i in range(1, nb):
-        for g in geoms_of[i]:
+    world_geoms = [c for c in doc.worldbody.children if c.tag == "geom"]  # (arena geoms such as a floor plane; none in the fly's own file)
+    for i in range(0, nb):
+        for g in (world_geoms if i == 0 else geoms_of[i]):
             a = doc.resolved(g)
             ct, ca = int(a.get("contype", 1)), int(a.get("conaffinity", 1))
             if ct == 0 and ca == 0:
@@ -1205,5 +1206,31 @@ def build_ball_model(assets_dir: str = REFERENCE_ASSETS, msh_dir: str = REFERENC
     ball.add(Element("joint", {"name": "ball", "type": "ball"}))
     doc.worldbody.children.insert(0, ball)
     m = compile_model(doc, assets_dir, msh_dir, timestep=2e-4, mesh_rule=mesh_rule, free_root=False)
+    m.walker = walker
+    return m
+
+
+def build_walk_model(assets_dir: str = REFERENCE_ASSETS, msh_dir: str = REFERENCE_MSH, mesh_rule: str = "legacy",
+                     joint_filter=0.01, adhesion_filter=0.007, claw_friction=1.0, floor_size=(8.0, 8.0, 0.25)) -> CompiledModel:
+    """The model `fly_envs.walk_imitation` compiles (`fly_envs.py:75-122`): the `Walking` configuration of the fly
+    (`tasks/base.py:331-364`: legs on, wings / mouth / antennae passive, filtered position actuators, 2e-4 s physics step)
+    on a free joint over dm_control's `floors.Floor()` (one plane geom at z = 0; dm_control is third-party and absent,
+    its default floor is restated: size 8 x 8, default contact dimension 3), with the ground-geom contact parameters of
+    `tasks/base.py:353-357` and the claw friction override of `tasks/walk_imitation.py:67-69`.  The ghost walker has no
+    contacts and only mirrors the reference pose (`walk_imitation.py:117-132`): it is not part of the compiled physics."""
+    doc = Document(os.path.join(assets_dir, "fruitfly.xml"))
+    fj = doc.find("freejoint", "free")
+    if fj is not None:
+        fj.remove()
+    wopt = WalkerOptions(use_legs=True, use_wings=False, use_mouth=False, use_antennae=False,
+                         joint_filter=joint_filter, adhesion_filter=adhesion_filter, num_user_actions=0)
+    walker = apply_walker_edits(doc, wopt)
+    if claw_friction is not None:
+        doc.classes["adhesion-collision"].own.setdefault("geom", {})["friction"] = str(claw_friction)
+    floor = Element("geom", {"name": "groundplane", "type": "plane", "size": np.asarray(floor_size, dtype=np.float64),
+                             "friction": "0.5 0.005 0.0001", "solref": "0.001 1", "solimp": "0.95 0.99 0.01",
+                             "contype": "1", "conaffinity": "1", "condim": "3"}, doc.worldbody)
+    doc.worldbody.children.insert(0, floor)
+    m = compile_model(doc, assets_dir, msh_dir, timestep=2e-4, mesh_rule=mesh_rule, free_root=True)
     m.walker = walker
     return m

@@ -118,6 +118,21 @@ def lib():
         L.fo_self_min_clear.argtypes = [vp, ip, ip]
         L.fo_convex_separation.restype = C.c_double
         L.fo_convex_separation.argtypes = [vp, vp, C.c_int, C.c_int, dp]
+        L.fo_walk_env_new.restype = vp
+        L.fo_walk_env_new.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, ip, C.c_int, ip, C.c_int, ip, dp, dp, dp, dp,
+                                      C.c_double, C.c_int, ip, dp, C.c_uint64, C.c_uint64, C.c_int]
+        L.fo_walk_env_data.restype = vp
+        L.fo_walk_env_data.argtypes = [vp]
+        L.fo_walk_env_set_pad_first_obs.argtypes = [vp, C.c_int]
+        L.fo_walk_env_request_reset.argtypes = [vp]
+        L.fo_walk_env_force_next.argtypes = [vp, C.c_int]
+        L.fo_walk_env_traj.restype = C.c_int
+        L.fo_walk_env_traj.argtypes = [vp]
+        L.fo_walk_obs_dim.restype = C.c_int
+        L.fo_walk_obs_dim.argtypes = [vp, C.c_int]
+        L.fo_walk_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
+        L.fo_walk_env_features.argtypes = [vp, dp, dp, dp, dp]
+        L.fo_walk_env_reward_factors.argtypes = [vp, C.c_int, dp]
         L.fo_env_counters.restype = C.c_int
         L.fo_env_counters.argtypes = [vp, ip, ip]
     return _lib
@@ -397,6 +412,73 @@ class OracleBallEnv:
         counts, gaps = np.zeros(n, dtype=np.int32), np.zeros(n)
         self.L.fo_ball_env_hist(self.ptr, _ip(counts), _dp(gaps), n)
         return counts, gaps
+
+    def split(self, obs):
+        out, o = {}, 0
+        for name, n in self.LAYOUT:
+            out[name] = obs[o : o + n]
+            o += n
+        return out
+
+
+class OracleWalkEnv:
+    """Single-instance float64 walk_imitation env (`fly_envs.py:75-122`); one call = one control step.  `refs` is a
+    `flybody_amd.tasks.walking.WalkRefSet`-like object (qpos, qvel, root2site, joint_quat, off); `mocap_jnt` / `mocap_site` index
+    the model's joints / sites; `retract` = (qpos addresses, values) written after the reference pose at reset."""
+
+    def __init__(self, model: OracleModel, refs, mocap_jnt, mocap_site, retract, *, control_timestep=2e-3, time_limit=10.0,
+                 future_steps=64, terminal_com_dist=0.3, seed=0, env_id=0, inference_mode=False):
+        self.model, self.L = model, model.L
+        keep = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        self._mj, self._ms = keep(mocap_jnt, np.int32), keep(mocap_site, np.int32)
+        self._off = keep(refs.off, np.int32)
+        self._rq, self._rv = keep(refs.qpos, np.float64), keep(refs.qvel, np.float64)
+        self._rs, self._rj = keep(refs.root2site, np.float64), keep(refs.joint_quat, np.float64)
+        self._oq, self._ov = keep(retract[0], np.int32), keep(retract[1], np.float64)
+        self.nmj, self.nms, self.future_steps = len(self._mj), len(self._ms), int(future_steps)
+        self.ptr = self.L.fo_walk_env_new(model.ptr, float(control_timestep), float(time_limit), self.future_steps, self.nmj,
+                                          _ip(self._mj), self.nms, _ip(self._ms), len(self._off) - 1, _ip(self._off), _dp(self._rq),
+                                          _dp(self._rv), _dp(self._rs), _dp(self._rj), float(terminal_com_dist), len(self._oq),
+                                          _ip(self._oq), _dp(self._ov), int(seed), int(env_id), int(inference_mode))
+        self.data = OracleData(model, self.L.fo_walk_env_data(self.ptr))
+        self.naction = model.naction
+        self.OBS = self.L.fo_walk_obs_dim(model.ptr, self.future_steps)
+        F = self.future_steps + 1
+        self.LAYOUT = (("accelerometer", 3), ("actuator_activation", model.na), ("appendages_pos", 21), ("force", 18), ("gyro", 3),
+                       ("joints_pos", 85), ("joints_vel", 85), ("ref_displacement", 3 * F), ("ref_root_quat", 4 * F), ("touch", 6),
+                       ("velocimeter", 3), ("world_zaxis", 3))
+
+    def set_pad_first_obs(self, v: bool):
+        self.L.fo_walk_env_set_pad_first_obs(self.ptr, int(v))
+
+    def force_next(self, traj_idx: int):
+        self.L.fo_walk_env_force_next(self.ptr, int(traj_idx))
+
+    @property
+    def traj_idx(self):
+        return self.L.fo_walk_env_traj(self.ptr)
+
+    def reset(self):
+        self.L.fo_walk_env_request_reset(self.ptr)
+        return self.step(np.zeros(self.naction))
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        obs = np.zeros(self.OBS)
+        r, dsc, st = C.c_double(), C.c_double(), C.c_int()
+        self.L.fo_walk_env_step(self.ptr, _dp(a), _dp(obs), C.byref(r), C.byref(dsc), C.byref(st))
+        return st.value, r.value, dsc.value, obs
+
+    def features(self):
+        com, qv = np.zeros(3), np.zeros(6 + self.nmj)
+        r2s, jq = np.zeros((self.nms, 3)), np.zeros((1 + self.nmj, 4))
+        self.L.fo_walk_env_features(self.ptr, _dp(com), _dp(qv), _dp(r2s), _dp(jq))
+        return {"com": com, "qvel": qv, "root2site": r2s, "joint_quat": jq}
+
+    def reward_factors(self, step: int):
+        out = np.zeros(4)
+        self.L.fo_walk_env_reward_factors(self.ptr, int(step), _dp(out))
+        return out
 
     def split(self, obs):
         out, o = {}, 0

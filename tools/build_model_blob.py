@@ -12,7 +12,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 from flybody_amd.model.blob import model_tensors, write_blob
-from flybody_amd.model.compiler import build_ball_model, build_flight_model
+from flybody_amd.model.compiler import build_ball_model, build_flight_model, build_walk_model
 
 OUT = os.path.join(os.path.dirname(__file__), "..", "flybody_amd", "assets")
 
@@ -54,6 +54,23 @@ def main():
     with open(os.path.join(OUT, "fly_ball.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote ball model: nbody", b.nbody, "nq", b.nq, "nv", b.nv, "nu", b.nu, "ngeom", len(b.geom_bodyid))
+    # fly_envs.walk_imitation: free-root walking fly on a floor plane.  The reference's walking dataset (absent) names the mocap
+    # joints and sites it tracks (trajectory_loaders.py:217-223); restated here as every leg joint and the six claw sites.
+    w = build_walk_model()
+    write_blob(os.path.join(OUT, "fly_walk.ffmb"), model_tensors(w, with_collision=True))
+    leg = [n for n in w.jnt_name if any(t in n for t in ("_T1_", "_T2_", "_T3_"))]
+    meta = {
+        "body_name": w.body_name, "jnt_name": w.jnt_name, "act_name": w.act_name, "ten_name": w.ten_name,
+        "geom_name": w.geom_name, "site_name": w.sites_name,
+        "observable_joints": w.walker["observable_joints"],
+        "action_names": [w.act_name[i] for c in ("adhesion", "head", "mouth", "antennae", "wings", "abdomen", "legs")
+                         for i in (w.walker["ctrl_indices"][c] or [])],
+        "mocap_joints": leg,
+        "mocap_sites": [n for n in w.sites_name if n.startswith("claw_")],
+    }
+    with open(os.path.join(OUT, "fly_walk.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote walk model: nbody", w.nbody, "nq", w.nq, "nv", w.nv, "nu", w.nu, "ngeom", len(w.geom_bodyid), "mocap joints", len(leg))
 
 
 if __name__ == "__main__":

@@ -154,8 +154,30 @@ def rewards_goldens():
     print("rewards.npz:", len(out), "arrays")
 
 
+def walker_feature_goldens():
+    """The quaternion helpers behind vnl_ray.tasks.rewards.get_walker_features (walk_imitation's reward): quat_z2vec (with its
+    edge cases), axis_angle_to_quat, joint_orientation_quat, get_egocentric_vec; and the exact sequence get_walker_features applies
+    to joint axes (rewards.py:45-52) on seeded stand-ins for physics.bind(...).xaxis / qpos."""
+    rng = np.random.RandomState(97)
+    n = 48
+    vec = rng.randn(n, 3)
+    vec[0] = [0.0, 0.0, 2.0]; vec[1] = [0.0, 0.0, -0.5]; vec[2] = [0.0, 0.0, 0.0]
+    ang = rng.uniform(-np.pi, np.pi, n)
+    root_quat = rng.randn(4); root_quat /= np.linalg.norm(root_quat)
+    root_pos, sites = rng.randn(3), rng.randn(6, 3)
+    xaxis = rng.randn(n, 3); xaxis /= np.linalg.norm(xaxis, axis=-1, keepdims=True)
+    local = RQ.rotate_vec_with_quat(xaxis, RQ.reciprocal_quat(root_quat))
+    out = {"vec": vec, "ang": ang, "z2vec": RQ.quat_z2vec(vec), "axis_angle": RQ.axis_angle_to_quat(xaxis, ang),
+           "joint_orientation": RQ.joint_orientation_quat(xaxis, ang), "root_quat": root_quat, "root_pos": root_pos, "sites": sites,
+           "egocentric": RQ.get_egocentric_vec(root_pos, sites, root_quat), "xaxis": xaxis,
+           "joint_quat_local": RQ.joint_orientation_quat(local, ang)}
+    np.savez_compressed(os.path.join(OUT, "walker_features.npz"), **out)
+    print("walker_features.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quaternion_goldens()
     wbpg_goldens()
     rewards_goldens()
+    walker_feature_goldens()
