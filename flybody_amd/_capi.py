@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("FLYBODY_ENV_LIB") or os.path.join(_HERE, "csrc", "lib
 
 SYMBOLS = [
     "ffe_create_flight", "ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_reset_envs", "ffe_step",
-    "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps",
+    "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps", "ffe_time_kernel",
     "ffe_test_quat", "ffe_last_error", "ffe_version", "ffe_create_walk_on_ball", "ffe_get_act", "ffe_set_act",
     "ffe_nstep_create", "ffe_nstep_observe", "ffe_nstep_buffers", "ffe_nstep_destroy", "ffe_nstep_last_error",
     "ffe_pack_timestep",
@@ -87,6 +87,7 @@ def lib():
     L.ffe_set_state.argtypes = [vp, dp, dp, vp]
     L.ffe_get_task_state.argtypes = [vp, ip, dp, vp]
     L.ffe_time_steps.argtypes = [vp, fp, fp, fp, fp, ip, C.c_int, vp, C.POINTER(C.c_float)]
+    L.ffe_time_kernel.argtypes = [vp, fp, fp, fp, fp, ip, C.c_int, vp, C.POINTER(C.c_float)]
     L.ffe_test_quat.argtypes = [C.c_int, fp, fp, fp, C.c_int, vp]
     L.ffe_nstep_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_longlong, C.c_int, C.POINTER(vp)]
     L.ffe_nstep_observe.argtypes = [vp, fp, ip, fp, fp, fp, vp]
@@ -102,7 +103,7 @@ def lib():
     L.ffe_last_error.argtypes = [vp]
     L.ffe_version.restype = C.c_char_p
     for s in ("ffe_destroy", "ffe_spec", "ffe_action_bounds", "ffe_reset", "ffe_reset_envs", "ffe_step", "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state",
-              "ffe_set_state", "ffe_get_task_state", "ffe_time_steps", "ffe_test_quat"):
+              "ffe_set_state", "ffe_get_task_state", "ffe_time_steps", "ffe_time_kernel", "ffe_test_quat"):
         getattr(L, s).restype = C.c_int
     _lib = L
     return L

@@ -272,6 +272,13 @@ class BatchedFlyEnv:
         self._check(self._L.ffe_get_task_state(self._h, ints.data_ptr(), reals.data_ptr(), self._stream()))
         return ints, reals
 
+    def time_kernel(self, action, iters: int) -> float:
+        """Mean milliseconds of the step kernel alone over `iters` launches (HIP events immediately around it)."""
+        ms = C.c_float()
+        self._check(self._L.ffe_time_kernel(self._h, action.data_ptr(), self._obs.data_ptr(), self._reward.data_ptr(),
+                                            self._discount.data_ptr(), self._step_type.data_ptr(), int(iters), self._stream(), C.byref(ms)))
+        return float(ms.value)
+
     def time_steps(self, action, iters: int) -> float:
         """Mean milliseconds per step launch over `iters` launches, by HIP events on the current stream."""
         ms = C.c_float()

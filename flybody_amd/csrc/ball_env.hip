@@ -1806,6 +1806,7 @@ struct BallEnv {
   BallModel *model_dev = nullptr;
   BState *states = nullptr;
   int *order = nullptr, *cost = nullptr;  // launch order of the envs and its sort keys (launch_order.hpp)
+  bool timing = false; double timing_ms = 0.0;  // ball_time_kernel: events around the step kernel alone
   double control_timestep = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -1857,12 +1858,20 @@ void ball_launch(BallEnv *e, const float *act, float *obs, float *rew, float *di
   if (mode != 1 && mode != 3 && !act) throw std::runtime_error("walk_on_ball: null action buffer");
   if (mode != 2 && (!obs || !rew || !disc || !st)) throw std::runtime_error("walk_on_ball: null output buffer");
   if (mode == 3 && !mask) throw std::runtime_error("walk_on_ball: null reset mask");
+  if (e->timing) HIPB_OK(hipEventRecord(e->ev0, (hipStream_t)stream));
   hipLaunchKernelGGL(ball_step_kernel, dim3(e->batch), dim3(64), 0, (hipStream_t)stream, e->model_dev, e->task, e->states, act, obs, rew, disc, st,
                      e->batch, mode, nphys, e->order, e->cost, mask);
   HIPB_OK(hipGetLastError());
+  if (e->timing) HIPB_OK(hipEventRecord(e->ev1, (hipStream_t)stream));
   if (mode == 0 && e->batch > 1) {
     hipLaunchKernelGGL(ffe_order::order_by_cost, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->cost, e->order, e->batch);
     HIPB_OK(hipGetLastError());
+  }
+  if (e->timing) {
+    float t = 0.f;
+    HIPB_OK(hipEventSynchronize(e->ev1));
+    HIPB_OK(hipEventElapsedTime(&t, e->ev0, e->ev1));
+    e->timing_ms += t;
   }
 }
 void ball_get_state(BallEnv *e, double *qpos, double *qvel, void *stream) {
@@ -1906,6 +1915,13 @@ float ball_time_steps(BallEnv *e, const float *act, float *obs, float *rew, floa
   float ms = 0.f;
   HIPB_OK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
   return ms / (float)iters;
+}
+
+float ball_time_kernel(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream) {
+  e->timing = true; e->timing_ms = 0.0;
+  for (int k = 0; k < iters; k++) ball_launch(e, act, obs, rew, disc, st, stream, 0, 0, nullptr);
+  e->timing = false;
+  return (float)(e->timing_ms / iters);
 }
 
 }  // namespace ffb

@@ -27,5 +27,6 @@ void ball_get_act(BallEnv *e, double *act, void *stream);
 void ball_set_act(BallEnv *e, const double *act, void *stream);
 void ball_get_task_state(BallEnv *e, int32_t *ints, double *reals, void *stream);
 float ball_time_steps(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream);
+float ball_time_kernel(BallEnv *e, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream);
 
 }  // namespace ffb

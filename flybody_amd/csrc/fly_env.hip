@@ -44,7 +44,9 @@ struct alignas(64) EnvState {
   // Position/velocity-stage results of the state above (dof axes, crb*axes, smooth joint forces, root frame, CoM): the
   // last stage-1 evaluation of a control step is exactly the first one of the next, so it is carried over instead of
   // being recomputed (bit-identical by construction; dropped whenever the state is written from outside).
-  int s1_valid, pad_[3];
+  int s1_valid;
+  int wb_off, wb_len, traj_row0;  // K.tab_off[wb_freq_idx], that table's length, K.traj_off[traj_idx]: kept with the state so that the
+                                  // next launch can address its table / reference rows straight from the record
   unsigned long long in_lo_mask, in_hi_mask;  // limits instantiated but resolved inactive by the last substep's solve (first guess of the next)
   unsigned char cost_hist[32];  // solver iterations of the last control step that ended in each of 32 wing-beat phase bins (launch order)
   float s1_cdof[kMaxDof * 6], s1_buf[kMaxDof * 6], s1_f[kLanePad], s1_misc[16];
@@ -1498,6 +1500,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   unsigned long long lo_mask = S.lo_mask, hi_mask = S.hi_mask, in_lo = S.in_lo_mask, in_hi = S.in_hi_mask;
   int wb_step = S.wb_step, wb_idx = S.wb_freq_idx, step_counter = S.step_counter, traj_idx = S.traj_idx;
   double wb_cf = S.wb_ctrl_freq;
+  int wb_off = S.wb_off, wb_len = S.wb_len, traj_row0 = S.traj_row0;
   const bool do_reset = !phys_only && ((mode == 1) || (S.needs_reset != 0));
   int iters = 0;
   // the stage-1 carry-over block of the previous launch (2.4 KB) depends on nothing the prologue computes: its loads are issued
@@ -1532,9 +1535,11 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     wb_cf = K.base_freq;
     wb_idx = wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane);
     int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
+    wb_off = off; wb_len = len;
     wb_step = wave_argmin_absdiff(K.phase + off, len, phase, lane);
     const int nxt = wb_step + 1 < len ? wb_step + 1 : 0;  // the reference reads [step+1] unguarded
     const int row0 = K.traj_off[traj_idx];
+    traj_row0 = row0;
     const double *rq = K.ref_qpos + (size_t)row0 * 7, *rv = K.ref_qvel + (size_t)row0 * 6;
     if (lane < kMaxDof + 4) { T.qpos[lane] = lane < M.nq ? M.qpos0[lane] : 0.f; T.qvel[lane] = 0.f; }
     SYNC();
@@ -1557,13 +1562,21 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     ctrl_reg = lane < M.nu ? act[(size_t)env * M.nu + lane] : 0.f;
     SYNC();
   } else {
-    if (lane < kMaxDof + 4) { T.qpos[lane] = S.qpos[lane]; T.qvel[lane] = S.qvel[lane]; }
-    SYNC();
-    // before_step (ref: flight_imitation.py:149-167, base.py:190-193, fruitfly.py:480-492)
+    // before_step (ref: flight_imitation.py:149-167, base.py:190-193, fruitfly.py:480-492).  Every global read whose address the
+    // state record already gives - the action entries, the wing-beat table row of the no-switch case, the reference rows - is
+    // issued here in one batch, next to the state's own vectors: the prologue is a chain of dependent memory round trips at the
+    // moment all resident waves start together, and each level removed from it is a microsecond or more per wave.
     const float *a_in = act + (size_t)env * M.naction;
+    const int ai = lane < M.nu ? M.a_action[lane] : -1;
+    float a_raw = ai >= 0 ? a_in[ai] : 0.f;
+    float au_raw = a_in[M.user_action];
+    const int step1 = wb_step + 1 < wb_len ? wb_step + 1 : 0;
+    float tgt = lane < M.nwing ? K.traj[(size_t)(wb_off + step1) * 6 + lane] : 0.f;  // (re-read below if the table switches)
+    const size_t row = (size_t)traj_row0 + step_counter;
+    const double gh = lane < 7 ? K.ref_qpos[row * 7 + lane] : (lane < 13 ? K.ref_qvel[row * 6 + (lane - 7)] : 0.0);
+    if (lane < kMaxDof + 4) { T.qpos[lane] = S.qpos[lane]; T.qvel[lane] = S.qvel[lane]; }
     // acme CanonicalSpecWrapper folded in (ref: train_dmpo_ray.py:128-129; tasks/task_utils.py:53-76 canonical2real)
-    auto read_action = [&](int k) -> float {
-      float v = a_in[k];
+    auto to_real = [&](float v, int k) -> float {
       if (!(v == v)) v = 0.f;  // NaN scrub
       if (K.canonical) {
         if (K.clip) v = fminf(fmaxf(v, -1.f), 1.f);
@@ -1571,31 +1584,28 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
       }
       return v;
     };
-    const float act_user = read_action(M.user_action);
+    const float act_user = to_real(au_raw, M.user_action);
     {
       // ref: pattern_generators.py:159-191 step
-      int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
-      wb_step = (wb_step + 1) % len;
+      wb_step = step1;
       wb_cf = wbpg_filter(wb_cf, K.rate, K.base_freq, K.rel_range, (double)act_user);
       int idx_new = DBG(c, DBG_SKIP_WBPG) ? wb_idx
                     : (K.grid_inv_step > 0.0 ? grid_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, K.grid_inv_step)
                                              : wave_argmin_absdiff(K.beat_freqs, K.nfreq, wb_cf, lane));
       if (idx_new != wb_idx) {
-        double cur = K.phase_frac[off + wb_step];
+        double cur = K.phase_frac[wb_off + wb_step];
         int noff = K.tab_off[idx_new], nlen = K.tab_off[idx_new + 1] - noff;
         wb_step = wave_argmin_absdiff(K.phase_frac + noff, nlen, cur, lane);
-        wb_idx = idx_new;
+        wb_idx = idx_new; wb_off = noff; wb_len = nlen;
+        if (lane < M.nwing) tgt = K.traj[(size_t)(wb_off + wb_step) * 6 + lane];
       }
     }
     STAMP(15);  // prologue up to the WBPG step
-    if (lane < M.nu) {
-      int ai = M.a_action[lane];
-      T.ctrl[lane] = ai >= 0 ? read_action(ai) : 0.f;
-    }
+    if (lane < M.nu) T.ctrl[lane] = ai >= 0 ? to_real(a_raw, ai) : 0.f;
+    if (lane < 13) T.ghost[lane] = gh;
     SYNC();
     if (lane < M.nwing) {
       // action[wings] += target - qpos[wing]; the wing actuators are the ctrl slots fed by those action entries
-      float tgt = K.traj[(size_t)(K.tab_off[wb_idx] + wb_step) * 6 + lane];
       float add = tgt - T.qpos[M.wing_qadr[lane]];
       const int u = M.wing_ctrl[lane];  // the ctrl slot fed by this wing's action entry
       if (u >= 0) T.ctrl[u] += add;
@@ -1603,10 +1613,6 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     SYNC();
     ctrl_reg = lane < M.nu ? T.ctrl[lane] : 0.f;
     SYNC();
-    const size_t row = (size_t)K.traj_off[traj_idx] + step_counter;
-    const double *rq = K.ref_qpos + row * 7, *rv = K.ref_qvel + row * 6;
-    if (lane < 7) T.ghost[lane] = rq[lane];
-    else if (lane < 13) T.ghost[lane] = rv[lane - 7];
     step_counter++;
   }
   // ---- physics.  dm_control's legacy step is mj_step2 then mj_step1, so the position/velocity stage is evaluated
@@ -1709,6 +1715,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   if (lane == 0) {
     S.rootpos[0] = T.rootpos[0]; S.rootpos[1] = T.rootpos[1]; S.rootpos[2] = T.rootpos[2];
     S.wb_ctrl_freq = wb_cf; S.wb_step = wb_step; S.wb_freq_idx = wb_idx; S.step_counter = step_counter; S.traj_idx = traj_idx;
+    S.wb_off = wb_off; S.wb_len = wb_len; S.traj_row0 = traj_row0;
     S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.in_lo_mask = in_lo; S.in_hi_mask = in_hi; S.solver_iters = iters;
     S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
     // Key of the next launch's order = the solver work the next step is expected to need.  Joint limits are hit at fixed
@@ -1808,6 +1815,7 @@ struct ffe_env {
   HostModel host;
   EnvState *states = nullptr;
   int *order = nullptr, *cost = nullptr;  // launch order of the envs and its sort keys (launch_order.hpp)
+  bool timing = false; double timing_ms = 0.0;  // ffe_time_kernel: events around the step kernel alone
   unsigned char *arena = nullptr;
   std::vector<void *> allocs;
   std::string err;
@@ -2021,16 +2029,23 @@ static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, f
   DeviceGuard guard(h->device);
   FFE_BALL_DISPATCH(h, ffb::ball_launch(h->ball, act, obs, rew, disc, st, stream, mode, nphys, mask));
   if (mode != 2 && (!obs || !rew || !disc || !st || (mode == 0 && !act))) { h->err = "null device buffer"; return -1; }
+  if (h->timing && hipEventRecord(h->ev0, static_cast<hipStream_t>(stream)) != hipSuccess) return -2;
   hipLaunchKernelGGL(flight_step_kernel, dim3(h->batch), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->dm_dev, h->task_dev, h->states, act, obs, rew,
                      disc, st, h->batch, mode, nphys, h->order, h->cost, mask);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
+  if (h->timing && hipEventRecord(h->ev1, static_cast<hipStream_t>(stream)) != hipSuccess) return -2;
   // measured: +2 % env-steps/s at B = 8 192 (two rounds of the 4 096 resident waves); beyond that the tail the order shortens
   // is a smaller share of the launch than the serialised sort kernel itself (-1.5 % at 16 384, -2 % at 32 768): not sorted
   if (mode == 0 && h->batch > 1 && h->batch <= 8192 && !(h->task.flags & DBG_NO_ORDER)) {
     hipLaunchKernelGGL(ffe_order::order_by_cost, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), h->cost, h->order, h->batch);
     e = hipGetLastError();
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
+  }
+  if (h->timing) {
+    float t = 0.f;
+    if (hipEventSynchronize(h->ev1) != hipSuccess || hipEventElapsedTime(&t, h->ev0, h->ev1) != hipSuccess) return -2;
+    h->timing_ms += t;
   }
   return 0;
 }
@@ -2113,6 +2128,18 @@ int ffe_time_steps(ffe_handle h, const float *act, float *obs, float *rew, float
   if (hipEventElapsedTime(&total, h->ev0, h->ev1) != hipSuccess) return -2;
   *ms = total / (float)iters;
   return 0;
+}
+
+int ffe_time_kernel(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, int iters, void *stream, float *ms) {
+  if (!h || !ms || iters <= 0) return -1;
+  DeviceGuard guard(h->device);
+  FFE_BALL_DISPATCH(h, *ms = ffb::ball_time_kernel(h->ball, act, obs, rew, disc, st, iters, stream));
+  h->timing = true; h->timing_ms = 0.0;
+  int rc = 0;
+  for (int i = 0; i < iters && !rc; i++) rc = launch_step(h, act, obs, rew, disc, st, stream, 0);
+  h->timing = false;
+  *ms = (float)(h->timing_ms / iters);
+  return rc;
 }
 
 #ifdef FFE_STAMPS

@@ -155,6 +155,11 @@ int ffe_get_task_state(ffe_handle h, int32_t *ints_dev, double *reals_dev, void 
  * and returns the mean milliseconds per ffe_step launch (synchronises the stream). */
 int ffe_time_steps(ffe_handle h, const float *act_dev, float *obs_dev, float *reward_dev, float *discount_dev,
                    int32_t *step_type_dev, int iters, void *stream, float *ms_per_step);
+/* the same for the step kernel alone (bench.py's roofline.kernel_ms; what rocprofv3 --kernel-trace reports for it): HIP events
+ * immediately around each of `iters` launches of the step kernel, without the launch-order kernel that follows it; synchronises
+ * after every launch */
+int ffe_time_kernel(ffe_handle h, const float *act_dev, float *obs_dev, float *reward_dev, float *discount_dev,
+                    int32_t *step_type_dev, int iters, void *stream, float *ms_per_kernel);
 
 /* device unit test of the in-kernel quaternion helpers against vnl_ray/quaternions.py goldens:
  * op 0 mult_quat(a,b) 1 reciprocal_quat(a) 2 rotate_vec_with_quat(a.xyz,b) 3 quat_dist_short_arc(a,b)

@@ -17,3 +17,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 cd $R && bash tools/pmc_ball.sh > $O/pmc_ball.log 2>&1; tail -2 $O/pmc_ball.log
 cd $R && bash tools/pmc_flight.sh > $O/pmc_flight.log 2>&1; tail -2 $O/pmc_flight.log
 cd $R && bash tools/batch_scaling.sh > $O/batch_scaling.log 2>&1; tail -3 $O/batch_scaling.log
+cd $R && timeout -k 10 200 python tools/wave_timeline.py flight 2>&1 | grep -v amdgpu > $O/wave_timeline_flight.log; timeout -k 10 300 python tools/wave_timeline.py ball 2>&1 | grep -v amdgpu > $O/wave_timeline_ball.log; head -3 $O/wave_timeline_ball.log
