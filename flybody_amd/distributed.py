@@ -24,7 +24,13 @@ class TimestepGather:
     def __init__(self, batch: int, obs_dim: int, device, world: int, rank: int):
         self.world, self.rank, self.obs_dim = world, rank, obs_dim
         self.pack = torch.empty(batch, obs_dim + 3, dtype=torch.float32, device=device)
-        self.out = [torch.empty_like(self.pack) for _ in range(world)] if (world > 1 and rank == 0) else None
+        # gloo gathers host tensors only: a device-resident env on a gloo group (CPU-side learner, or the one-GPU rehearsal of the
+        # sharded path in tests/test_gpu_sharded.py) stages the packed buffer through pinned host memory; RCCL takes it as it is
+        self.stage = None
+        if world > 1 and self.pack.is_cuda and dist.get_backend() == "gloo":
+            self.stage = torch.empty(batch, obs_dim + 3, dtype=torch.float32, pin_memory=True)
+        like = self.stage if self.stage is not None else self.pack
+        self.out = [torch.empty_like(like) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def __call__(self, obs, reward, discount, step_type, async_op: bool = False):
         """Packs and gathers.  With `async_op` the collective runs on RCCL's own stream and the returned work handle
@@ -45,6 +51,9 @@ class TimestepGather:
             p[:, -2] = discount
             p[:, -1] = step_type.to(torch.float32)
         if self.world > 1:
+            if self.stage is not None:
+                self.stage.copy_(p)  # (synchronises the env's stream)
+                p = self.stage
             work = dist.gather(p, self.out, dst=0, async_op=async_op)
             if async_op:
                 return work

@@ -620,6 +620,31 @@ def test_shards_reproduce_the_single_handle(torch_mod, wb_tables, ref_traj):
         e.close()
 
 
+def test_launch_order_does_not_change_results(torch_mod, wb_tables, ref_traj):
+    """The step kernel visits the envs in the order the cost predictor of the previous step filed them (launch_order.hpp, the
+    wing-beat-phase histogram in the state record); envs are independent, so a handle stepped in plain index order
+    (flag 1 << 24) must produce the same bits."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+
+    torch = torch_mod
+    B = 1024
+    a_env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=11)
+    b_env = BatchedFlyEnv(wb_tables, *ref_traj, batch_size=B, seed=11, physics_flags=1 << 24)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lo, hi = (torch.tensor(x, device="cuda") for x in a_env.raw_action_bounds())
+    ta, tb = a_env.reset(), b_env.reset()
+    for k in range(150):
+        assert torch.equal(a_env.flat_observation, b_env.flat_observation), k
+        assert torch.equal(ta.reward, tb.reward) and torch.equal(ta.step_type, tb.step_type) and torch.equal(ta.discount, tb.discount), k
+        a = (lo + (hi - lo) * torch.rand(B, 12, device="cuda", generator=g)).contiguous()
+        ta, tb = a_env.step(a), b_env.step(a)
+    ia, _ = a_env.get_task_state()
+    ib, _ = b_env.get_task_state()
+    assert torch.equal(ia, ib)  # WBPG state, counters, active limits, solver passes
+    assert int((ia[:, 6] > 0).sum()) > 0  # the constraint solver was exercised
+    a_env.close(); b_env.close()
+
+
 def test_trajectories_of_different_lengths(torch_mod, wb_tables, ref_traj):
     """The reference serves trajectories of individual lengths (trajectory_loaders.py:98-100) and ends an episode at
     min(len(traj), round(time_limit / dt)) - (future_steps + 1) of the trajectory it drew (flight_imitation.py:107-108):
