@@ -275,7 +275,9 @@ def main():
     # dominant kernel: mean launch duration by HIP events on the launch stream, same workload
     # kernel_ms = HIP events immediately around each launch of the step kernel alone (ffe_time_kernel: the duration rocprofv3's
     # kernel trace reports for it); the timed region's own events also span the 6-12 us launch-order kernel that follows every step
-    k_ms = env.time_kernel(acts[0], min(args.steps, 100)) if hasattr(env, "time_kernel") else env.time_steps(acts[0], min(args.steps, 100))
+    # (one launch per call, cycling through the same action pool as the timed region: same workload)
+    nk = min(args.steps, 100)
+    k_ms = (sum(env.time_kernel(acts[k % npool], 1) for k in range(nk)) / nk) if hasattr(env, "time_kernel") else env.time_steps(acts[0], nk)
     sync()
     k_ms_region = ev0.elapsed_time(ev1) / args.steps if ev0 is not None else k_ms
 

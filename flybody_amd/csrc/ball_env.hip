@@ -369,26 +369,25 @@ __device__ __forceinline__ float impedance(const float *si, float x) {
 __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane, const int nc) {
   BTile &T = *Tp;
   const BallModel FFE_GLOBAL &M = *Mp;
-  const float(*pg)[8] = reinterpret_cast<const float(*)[8]>(&T.lk[0][0]);
+  const float4 *pgc = reinterpret_cast<const float4 *>(&T.lk[0][0]), *pga = pgc + NPG;  // (centre, radius) and (axis, half length) per slot
   const float mclaw = M.sc_margin;
   const unsigned long long claws = M.sp_claw;
   const int sphere = M.sp_sphere;
   // lane s owns slot s and meets slots s + 1 .. s + NPG / 2 (mod NPG): every unordered pair once
   const bool own = lane < NPG;
   const unsigned long long partners = own ? M.sp_mask[lane] : 0ull;
-  const float4 o0 = own ? *reinterpret_cast<const float4 *>(&pg[lane][0]) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 o1 = own ? *reinterpret_cast<const float4 *>(&pg[lane][4]) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float oreach = o1.z + o1.w + (((claws >> lane) & 1ull) ? mclaw : 0.f);
+  const float4 o0 = own ? pgc[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float oreach = (own ? pga[lane].w : 0.f) + o0.w + (((claws >> lane) & 1ull) ? mclaw : 0.f);
   unsigned near = 0u;  // bit t - 1: the pair (lane, lane + t) passed the bounding-sphere test
 #pragma unroll 4
   for (int t = 1; t <= NPG / 2; t++) {
     int j = lane + t;
     j = j >= NPG ? j - NPG : j;
     if (own && ((partners >> j) & 1ull) && (t < NPG / 2 || lane < NPG / 2)) {
-      const float4 p0 = *reinterpret_cast<const float4 *>(&pg[j][0]);
-      const float2 p1 = *reinterpret_cast<const float2 *>(&pg[j][6]);
+      const float4 p0 = pgc[j];
+      const float ph = pga[j].w;
       const float dx = p0.x - o0.x, dy = p0.y - o0.y, dz = p0.z - o0.z;
-      const float reach = oreach + p1.x + p1.y + mclaw;  // (the claw margin on both sides: a bound is all that is needed here)
+      const float reach = oreach + ph + p0.w + mclaw;  // (the claw margin on both sides: a bound is all that is needed here)
       if (dx * dx + dy * dy + dz * dz <= reach * reach) near |= 1u << (t - 1);
     }
   }
@@ -407,9 +406,9 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
       // mj: geom1 is the one with the lower type code (the sphere), else the one that comes first in the model
       const bool swap = j == sphere || (lane != sphere && j < lane);
       s1 = swap ? j : lane; s2 = swap ? lane : j;
-      const float *a = pg[s1], *b = pg[s2];
-      const V3 p1 = {a[0], a[1], a[2]}, a1 = {a[3], a[4], a[5]}, p2 = {b[0], b[1], b[2]}, a2 = {b[3], b[4], b[5]};
-      const float l1 = a[6], r1 = a[7], l2 = b[6], r2 = b[7];
+      const float4 ca = pgc[s1], aa = pga[s1], cb_ = pgc[s2], ab = pga[s2];
+      const V3 p1 = {ca.x, ca.y, ca.z}, a1 = {aa.x, aa.y, aa.z}, p2 = {cb_.x, cb_.y, cb_.z}, a2 = {ab.x, ab.y, ab.z};
+      const float l1 = aa.w, r1 = ca.w, l2 = ab.w, r2 = cb_.w;
       margin = (((claws >> s1) | (claws >> s2)) & 1ull) ? mclaw : 0.f;
       const V3 dif = p1 - p2;
       const float mb = -dot(a1, a2), u = -dot(a1, dif), v = dot(a2, dif), det = 1.f - mb * mb;
@@ -795,9 +794,11 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     const V3 ax = mv(xmat, V3{M.g_axis[0][lane], M.g_axis[1][lane], M.g_axis[2][lane]});
     const float half = M.g_half[lane], rad = M.g_rad[lane], x = fminf(fmaxf(dot(ax, bc - gp), -half), half);
     {  // publish the geom for the fly-fly pair tests below (the link-exchange area is free between the factorisation and stage 2)
-      float *o = reinterpret_cast<float(*)[8]>(&T.lk[0][0])[M.g_slot[lane]];
-      *reinterpret_cast<float4 *>(o) = make_float4(gp.x, gp.y, gp.z, ax.x);
-      *reinterpret_cast<float4 *>(o + 4) = make_float4(ax.y, ax.z, half, rad);
+      // two float4 arrays (centre | radius, axis | half length), slot-major: consecutive lanes read consecutive 16-byte words
+      float4 *o = reinterpret_cast<float4 *>(&T.lk[0][0]);
+      const int sl = M.g_slot[lane];
+      o[sl] = make_float4(gp.x, gp.y, gp.z, rad);
+      o[NPG + sl] = make_float4(ax.x, ax.y, ax.z, half);
     }
     margin = M.g_margin[lane]; gap = M.g_gap[lane];
     const V3 dif = gp + x * ax - bc;
@@ -847,9 +848,9 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     if (lane == M.pg2_lane) {  // the rostrum's second capsule
       const V3 gc = c.xp + mv(xmat, V3{M.pg2_pos[0], M.pg2_pos[1], M.pg2_pos[2]});
       const V3 ga = mv(xmat, V3{M.pg2_axis[0], M.pg2_axis[1], M.pg2_axis[2]});
-      float *o = reinterpret_cast<float(*)[8]>(&T.lk[0][0])[M.pg2_slot];
-      *reinterpret_cast<float4 *>(o) = make_float4(gc.x, gc.y, gc.z, ga.x);
-      *reinterpret_cast<float4 *>(o + 4) = make_float4(ga.y, ga.z, M.pg2_half, M.pg2_rad);
+      float4 *o = reinterpret_cast<float4 *>(&T.lk[0][0]);
+      o[M.pg2_slot] = make_float4(gc.x, gc.y, gc.z, M.pg2_rad);
+      o[NPG + M.pg2_slot] = make_float4(ga.x, ga.y, ga.z, M.pg2_half);
     }
     DM_SYNC();
 #ifdef FFB_SC_NOCALL
