@@ -647,317 +647,17 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     st6(T.buf[lane], mul_inert(ld10(T.crb[d_link]), cd2));
   }
   SYNC();
-  // M(i,j) = cdof_j . (crb_i cdof_i) is formed directly into the factor's working copy (see factor)
+  // M(i,j) = cdof_j . (crb_i cdof_i) is formed directly into the factor's working copy (see bfactor)
   STAMP(3);  // subtree sums + joint space
 }
 
 
-// mj: mj_factorI on (M + diag(add)).  Tree-sparse L'DL in MuJoCo's row layout (row i = [M(i,i), M(i,parent), ...]);
-// rows are left unscaled and 1/D is kept per lane (c.dinv).  Pivots run leaf -> root; pivot k with n ancestors
-// a_1..a_n applies M(a_s,a_t) -= M(k,a_s) M(k,a_t) / M(k,k) for s <= t.  Lanes own (s,t) pairs in an enumeration
-// sorted by t, so the pairs of any pivot are a prefix and live in registers for the whole kernel; every address is
-// arithmetic or an LDS lookup - no global memory inside the dependent chain.
-// A substep needs two factorisations of the same sparsity that differ only in their diagonals (the constraint Hessian
-// M + D_active and the implicit-damping matrix M + h B).  DUAL factors both in one sweep: entries are float2, so the
-// LDS instruction count and all index arithmetic are those of a single factorisation.  Non-DUAL refactors slot .x only
-// (an active-set change) and leaves the Euler factor in .y untouched.
-template <bool DUAL>
-__device__ __forceinline__ void factor(Ctx &c, float add0, float add1) {
-  const DevModel FFE_CONST &M = model(c);
-  Tile &T = c.T;
-  const int lane = c.lane;
-  const int nv = M.nv;
-  const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f;
-  unsigned pr[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) pr[r] = M.pairtab[lane + r * kWave];
-  STAMP(6);
-  // mj_crb: M(i,j) = cdof_j . (crb_i cdof_i) over the 421 ancestor pairs, written straight into the working copy
-  // (cdof and crb*cdof stay in LDS for the whole substep, so a refactorisation simply forms the entries again)
-  {
-    int ei[7], ej[7];
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      const int e = lane + r * kWave;
-      const bool ok = e < M.nM;
-      ei[r] = ok ? M.m_row[e] : 0;
-      ej[r] = ok ? M.m_col[e] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      const int e = lane + r * kWave;
-      if (e < M.nM) {
-        float m = dot6(ld6a(T.cdof[ej[r]]), ld6a(T.buf[ei[r]]));
-        if (ei[r] == ej[r]) m += M.d_arm[ei[r]] + (DBG(c, DBG_SKIP_MENTRIES) ? 1.f : 0.f);
-        if (DUAL) T.LD[e] = make_float2(m, m); else T.LD[e].x = m;
-      }
-    }
-  }
-  SYNC();
-  if (lane < nv) {
-    T.LD[d_madr].x += add0;
-    if (DUAL) T.LD[d_madr].y += add1;
-  }
-  SYNC();
-  STAMP(4);  // M entries
-  if (DBG(c, DBG_SKIP_FACTOR)) {
-    c.dinv[0] = lane < nv ? 1.0f / T.LD[d_madr].x : 0.f;
-    if (DUAL) c.dinv[1] = lane < nv ? 1.0f / T.LD[d_madr].y : 0.f;
-    return;
-  }
-#pragma unroll 1
-  for (int k = nv - 1; k > 0; k--) {
-    const int n = rl_i(d_depth, k) - 1;
-    const int mk = rl_i(d_madr, k);
-    const int cnt = (n * (n + 1)) >> 1;
-    float2 piv;
-    if (DUAL) piv = T.LD[mk]; else piv.x = T.LD[mk].x;
-    const float inv0 = __builtin_amdgcn_rcpf(piv.x);
-    const float inv1 = DUAL ? __builtin_amdgcn_rcpf(piv.y) : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (r * kWave < cnt) {  // wave-uniform
-        if (lane + r * kWave < cnt) {
-          const int sidx = pr[r] & 0xff, tidx = pr[r] >> 8;
-          const int tgt = (int)T.colmadr[mk + sidx] + (tidx - sidx);
-          if (DUAL) {
-            const float2 a = T.LD[mk + sidx], b = T.LD[mk + tidx];
-            float2 t = T.LD[tgt];
-            t.x -= a.x * inv0 * b.x;
-            t.y -= a.y * inv1 * b.y;
-            T.LD[tgt] = t;
-          } else {
-            T.LD[tgt].x -= T.LD[mk + sidx].x * inv0 * T.LD[mk + tidx].x;
-          }
-        }
-      }
-    }
-    SYNC();
-  }
-  if (DUAL) {
-    const float2 d = T.LD[d_madr];
-    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(d.x) : 0.f;
-    c.dinv[1] = lane < nv ? __builtin_amdgcn_rcpf(d.y) : 0.f;
-  } else {
-    c.dinv[0] = lane < nv ? __builtin_amdgcn_rcpf(T.LD[d_madr].x) : 0.f;
-  }
-  STAMP(5);  // elimination
-}
-
-// mj: mj_solveLD with the factor above; the vector lives in registers (one dof per lane) and travels by readlane,
-// the factor is only read, so there is no barrier inside the two sweeps.
-template <int COMP>
-__device__ __forceinline__ float solve(Ctx &c, float rhs) {
-  const DevModel FFE_CONST &M = model(c);
-  Tile &T = c.T;
-  const int lane = c.lane;
-  const int nv = M.nv;
-  const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
-  const bool is_dof = lane < nv;
-  const float dinv = c.dinv[COMP];
-  const float *LDc = reinterpret_cast<const float *>(T.LD) + COMP;  // entry e of this factor sits at LDc[2 e]
-  if (DBG(c, DBG_SKIP_SOLVE)) return is_dof ? rhs * dinv : 0.f;
-  STAMP(6);  // stage-2 glue before a solve
-  float x = is_dof ? rhs : 0.f;
-  const int my_end = lane + d_ndesc;         // last descendant dof of this lane
-  const int my_md = d_madr + d_depth;      // so that row-entry addresses become (my_md - depth_of_column)
-  const int dep = d_depth;
-  // x <- L^-T x : pivots from the leaves to the root; the ancestors of i (lanes j with j < i <= j + ndesc_j) fold it
-  // in.  The factor entries do not depend on x, so they are fetched four pivots ahead of the dependent chain.
-  int i = nv - 1;
-#pragma unroll 1
-  for (; i >= 4; i -= 4) {
-    const bool p0 = lane < i && i <= my_end, p1 = lane < i - 1 && i - 1 <= my_end, p2 = lane < i - 2 && i - 2 <= my_end,
-               p3 = lane < i - 3 && i - 3 <= my_end;
-    const float l0 = p0 ? LDc[2 * (rl_i(my_md, i) - dep)] : 0.f, l1 = p1 ? LDc[2 * (rl_i(my_md, i - 1) - dep)] : 0.f,
-                l2 = p2 ? LDc[2 * (rl_i(my_md, i - 2) - dep)] : 0.f, l3 = p3 ? LDc[2 * (rl_i(my_md, i - 3) - dep)] : 0.f;
-    x -= l0 * (rl_f(x, i) * rl_f(dinv, i));
-    x -= l1 * (rl_f(x, i - 1) * rl_f(dinv, i - 1));
-    x -= l2 * (rl_f(x, i - 2) * rl_f(dinv, i - 2));
-    x -= l3 * (rl_f(x, i - 3) * rl_f(dinv, i - 3));
-  }
-#pragma unroll 1
-  for (; i > 0; i--) {
-    const float l0 = (lane < i && i <= my_end) ? LDc[2 * (rl_i(my_md, i) - dep)] : 0.f;
-    x -= l0 * (rl_f(x, i) * rl_f(dinv, i));
-  }
-  // x <- D^-1 x
-  x *= dinv;
-  // x <- L^-1 x : from the root down; every descendant i of j (j < i <= j + ndesc_j) subtracts L(i,j) x_j
-  int j = 0;
-#pragma unroll 1
-  for (; j + 4 <= nv - 1; j += 4) {
-    const bool p0 = lane > j && lane <= rl_i(my_end, j), p1 = lane > j + 1 && lane <= rl_i(my_end, j + 1),
-               p2 = lane > j + 2 && lane <= rl_i(my_end, j + 2), p3 = lane > j + 3 && lane <= rl_i(my_end, j + 3);
-    const float l0 = p0 ? LDc[2 * (my_md - rl_i(dep, j))] * dinv : 0.f, l1 = p1 ? LDc[2 * (my_md - rl_i(dep, j + 1))] * dinv : 0.f,
-                l2 = p2 ? LDc[2 * (my_md - rl_i(dep, j + 2))] * dinv : 0.f, l3 = p3 ? LDc[2 * (my_md - rl_i(dep, j + 3))] * dinv : 0.f;
-    x -= l0 * rl_f(x, j);
-    x -= l1 * rl_f(x, j + 1);
-    x -= l2 * rl_f(x, j + 2);
-    x -= l3 * rl_f(x, j + 3);
-  }
-#pragma unroll 1
-  for (; j < nv - 1; j++) {
-    const float l0 = (lane > j && lane <= rl_i(my_end, j)) ? LDc[2 * (my_md - rl_i(dep, j))] * dinv : 0.f;
-    x -= l0 * rl_f(x, j);
-  }
-  STAMP(7);  // triangular solves
-  return x;
-}
-
-// The common case (no joint limit instantiated, ~3/4 of all substeps with random actions): factor M and M + h B and
-// solve both against the same right-hand side f, with the leaf-to-root substitution (x <- L^-T x) folded into the
-// elimination sweep - pivot k's row and x_k are final exactly when the sweep reaches k, so each pivot also pushes
-// x_k to its ancestors.  Saves the 41 dependent steps of a separate forward substitution.
-__device__ __forceinline__ float2 factor_solve_both(Ctx &c, float hB, float rhs) {
-  const DevModel FFE_CONST &M = model(c);
-  Tile &T = c.T;
-  const int lane = c.lane;
-  const int nv = M.nv;
-  const bool is_dof = lane < nv;
-  const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
-  unsigned pr[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) pr[r] = M.pairtab[lane + r * kWave];
-  STAMP(6);
-  {
-    int ei[7], ej[7];
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      const int e = lane + r * kWave;
-      const bool ok = e < M.nM;
-      ei[r] = ok ? M.m_row[e] : 0;
-      ej[r] = ok ? M.m_col[e] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      const int e = lane + r * kWave;
-      if (e < M.nM) {
-        float m = dot6(ld6a(T.cdof[ej[r]]), ld6a(T.buf[ei[r]]));
-        if (ei[r] == ej[r]) m += M.d_arm[ei[r]];
-        T.LD[e] = make_float2(m, m);
-      }
-    }
-  }
-  SYNC();
-  if (is_dof) T.LD[d_madr].y += hB;
-  SYNC();
-  STAMP(4);
-  float x0 = is_dof ? rhs : 0.f, x1 = x0;
-  const int my_end = lane + d_ndesc, my_md = d_madr + d_depth, dep = d_depth;
-#pragma unroll 1
-  for (int k = nv - 1; k > 0; k--) {
-    const int md_k = rl_i(my_md, k);
-    const int n = md_k - rl_i(d_madr, k) - 1;
-    const int mk = md_k - n - 1;
-    const int cnt = (n * (n + 1)) >> 1;
-    const float2 piv = T.LD[mk];
-    const float inv0 = __builtin_amdgcn_rcpf(piv.x), inv1 = __builtin_amdgcn_rcpf(piv.y);
-    // forward substitution step for pivot k (reads row k before this pivot's own updates touch other rows)
-    {
-      const bool anc = lane < k && k <= my_end;
-      const float2 l = anc ? T.LD[md_k - dep] : make_float2(0.f, 0.f);
-      x0 -= l.x * (inv0 * rl_f(x0, k));
-      x1 -= l.y * (inv1 * rl_f(x1, k));
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (r * kWave < cnt) {  // wave-uniform
-        if (lane + r * kWave < cnt) {
-          const int sidx = pr[r] & 0xff, tidx = pr[r] >> 8;
-          const int tgt = (int)T.colmadr[mk + sidx] + (tidx - sidx);
-          const float2 a = T.LD[mk + sidx], b = T.LD[mk + tidx];
-          float2 t = T.LD[tgt];
-          t.x -= a.x * inv0 * b.x;
-          t.y -= a.y * inv1 * b.y;
-          T.LD[tgt] = t;
-        }
-      }
-    }
-    SYNC();
-  }
-  const float2 dd = T.LD[d_madr];
-  const float di0 = is_dof ? __builtin_amdgcn_rcpf(dd.x) : 0.f, di1 = is_dof ? __builtin_amdgcn_rcpf(dd.y) : 0.f;
-  c.dinv[0] = di0; c.dinv[1] = di1;
-  STAMP(5);
-  x0 *= di0; x1 *= di1;
-  // x <- L^-1 x : from the root down
-  const float2 z2 = make_float2(0.f, 0.f);
-  int j = 0;
-#pragma unroll 1
-  for (; j + 2 <= nv - 1; j += 2) {
-    const bool p0 = lane > j && lane <= rl_i(my_end, j), p1 = lane > j + 1 && lane <= rl_i(my_end, j + 1);
-    const float2 l0 = p0 ? T.LD[my_md - rl_i(dep, j)] : z2, l1 = p1 ? T.LD[my_md - rl_i(dep, j + 1)] : z2;
-    x0 -= l0.x * di0 * rl_f(x0, j);
-    x1 -= l0.y * di1 * rl_f(x1, j);
-    x0 -= l1.x * di0 * rl_f(x0, j + 1);
-    x1 -= l1.y * di1 * rl_f(x1, j + 1);
-  }
-#pragma unroll 1
-  for (; j < nv - 1; j++) {
-    const float2 l0 = (lane > j && lane <= rl_i(my_end, j)) ? T.LD[my_md - rl_i(dep, j)] : z2;
-    x0 -= l0.x * di0 * rl_f(x0, j);
-    x1 -= l0.y * di1 * rl_f(x1, j);
-  }
-  STAMP(7);
-  return make_float2(x0, x1);
-}
-
-// Both resident factors applied to the same right-hand side in one pair of sweeps (float2 factor entries, shared
-// predicates and index arithmetic): used when no joint limit is instantiated, where qacc = M^-1 f and the Euler
-// acceleration (M + h B)^-1 f differ only in the factor.
-__device__ __forceinline__ float2 solve_both(Ctx &c, float rhs) {
-  const DevModel FFE_CONST &M = model(c);
-  Tile &T = c.T;
-  const int lane = c.lane;
-  const int nv = M.nv;
-  const bool is_dof = lane < nv;
-  const int d_madr = c.la_pack & 0x3ff, d_depth = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
-  const float di0 = c.dinv[0], di1 = c.dinv[1];
-  if (DBG(c, DBG_SKIP_SOLVE)) return is_dof ? make_float2(rhs * di0, rhs * di1) : make_float2(0.f, 0.f);
-  STAMP(6);
-  float x0 = is_dof ? rhs : 0.f, x1 = x0;
-  const int my_end = lane + d_ndesc, my_md = d_madr + d_depth, dep = d_depth;
-  const float2 z2 = make_float2(0.f, 0.f);
-  int i = nv - 1;
-#pragma unroll 1
-  for (; i >= 2; i -= 2) {
-    const bool p0 = lane < i && i <= my_end, p1 = lane < i - 1 && i - 1 <= my_end;
-    const float2 l0 = p0 ? T.LD[rl_i(my_md, i) - dep] : z2, l1 = p1 ? T.LD[rl_i(my_md, i - 1) - dep] : z2;
-    x0 -= l0.x * (rl_f(x0, i) * rl_f(di0, i));
-    x1 -= l0.y * (rl_f(x1, i) * rl_f(di1, i));
-    x0 -= l1.x * (rl_f(x0, i - 1) * rl_f(di0, i - 1));
-    x1 -= l1.y * (rl_f(x1, i - 1) * rl_f(di1, i - 1));
-  }
-#pragma unroll 1
-  for (; i > 0; i--) {
-    const float2 l0 = (lane < i && i <= my_end) ? T.LD[rl_i(my_md, i) - dep] : z2;
-    x0 -= l0.x * (rl_f(x0, i) * rl_f(di0, i));
-    x1 -= l0.y * (rl_f(x1, i) * rl_f(di1, i));
-  }
-  x0 *= di0; x1 *= di1;
-  int j = 0;
-#pragma unroll 1
-  for (; j + 2 <= nv - 1; j += 2) {
-    const bool p0 = lane > j && lane <= rl_i(my_end, j), p1 = lane > j + 1 && lane <= rl_i(my_end, j + 1);
-    const float2 l0 = p0 ? T.LD[my_md - rl_i(dep, j)] : z2, l1 = p1 ? T.LD[my_md - rl_i(dep, j + 1)] : z2;
-    x0 -= l0.x * di0 * rl_f(x0, j);
-    x1 -= l0.y * di1 * rl_f(x1, j);
-    x0 -= l1.x * di0 * rl_f(x0, j + 1);
-    x1 -= l1.y * di1 * rl_f(x1, j + 1);
-  }
-#pragma unroll 1
-  for (; j < nv - 1; j++) {
-    const float2 l0 = (lane > j && lane <= rl_i(my_end, j)) ? T.LD[my_md - rl_i(dep, j)] : z2;
-    x0 -= l0.x * di0 * rl_f(x0, j);
-    x1 -= l0.y * di1 * rl_f(x1, j);
-  }
-  STAMP(7);
-  return make_float2(x0, x1);
-}
-
-
-// mj: mj_factorI, branch-parallel (same tree-sparse L'DL, same row layout and 1/D convention as `factor` above).  The dofs
+// mj: mj_factorI on (M + diag(add)), branch-parallel.  Tree-sparse L'DL in MuJoCo's row layout (row i = [M(i,i), M(i,parent), ...]);
+// rows are left unscaled and 1/D is kept per lane (c.dinv).  Pivot k with ancestors a_1..a_n applies
+// M(a_s,a_t) -= M(k,a_s) M(k,a_t) / M(k,k) for s <= t.  A substep needs two factorisations of the same sparsity that differ only
+// in their diagonals (the constraint Hessian M + D_active and the implicit-damping matrix M + h B): DUAL factors both in one
+// sweep (entries are float2, so the LDS instruction count and all index arithmetic are those of a single factorisation);
+// non-DUAL refactors slot .x only (an active-set change) and leaves the Euler factor in .y untouched.  The dofs
 // behind the free joint's root chain split into independent branches, so step t eliminates the t-th pivot of EVERY branch:
 // 14 dependent steps + 5 for the root chain instead of 41.  The pair updates of a step's pivots are dealt over the 64 lanes in
 // rounds by a host-built schedule (DevModel::fsched, one coalesced word per lane and round, fetched one round ahead);
@@ -1227,35 +927,17 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   const float hB = (is_dof && want_euler) ? h * M.d_damp[lane] : 0.f;
   if (ex_any == 0ULL) {
     // no limit instantiated: one dual factorisation, one dual solve
-#ifdef FFE_OLD_SOLVE
-    if (want_euler && !DBG(c, DBG_SKIP_FACTOR | DBG_SKIP_SOLVE)) { const float2 r = factor_solve_both(c, hB, f); a = r.x; ae = r.y; }
-    else {
-      factor<true>(c, 0.f, hB);
-      if (want_euler) { const float2 r = solve_both(c, f); a = r.x; ae = r.y; }
-      else { a = solve<0>(c, f); ae = a; }
-    }
-#else
     bfactor<true>(c, 0.f, hB);
     if (want_euler) { const float2 r = bsolve<2>(c, f); a = r.x; ae = r.y; }
     else { a = bsolve<0>(c, f).x; ae = a; }
-#endif
   } else {
 #pragma unroll 1
     for (int it = 0; it < 8; it++) {
       const float add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
       const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
-#ifdef FFE_OLD_SOLVE
-      if (it == 0) factor<true>(c, add, hB);   // constraint Hessian and Euler matrix in one sweep
-      else factor<false>(c, add, 0.f);          // active set changed: refactor the Hessian only
-#else
       if (it == 0) bfactor<true>(c, add, hB);
       else bfactor<false>(c, add, 0.f);
-#endif
-#ifdef FFE_OLD_SOLVE
-      a = solve<0>(c, rhs);
-#else
       a = bsolve<0>(c, rhs).x;
-#endif
       iters++;
       const bool n_lo = ex_lo && (a - ar_lo < 0.f);
       const bool n_hi = ex_hi && (-a - ar_hi < 0.f);
@@ -1265,11 +947,7 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
     }
     if (act_lo) fc += D_lo * (ar_lo - a);
     if (act_hi) fc -= D_hi * (ar_hi + a);
-#ifdef FFE_OLD_SOLVE
-    ae = want_euler ? solve<1>(c, f + fc) : a;
-#else
     ae = want_euler ? bsolve<1>(c, f + fc).y : a;
-#endif
   }
   STAMP(14);  // (remaining glue inside the constraint/Euler block)
   lo_mask = __ballot(act_lo);
