@@ -812,7 +812,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   const int idx = __popcll(bal & ((1ull << lane) - 1ull));
   c.nc = min(__popcll(bal), NC);
   c.nact = __popcll(__ballot(hit && idx < NC && !(dist >= margin - gap)));
-  if (__popcll(bal) > NC) c.overflow = 1;  // more contacts than the tile holds: the extra ones are dropped and the env is flagged
+  if (__popcll(bal) > NC) c.overflow |= 1;  // more contacts than the tile holds: the extra ones are dropped and the env is flagged
   if (hit && idx < NC) {
     T.c_link[idx] = lane;
     const int last = ndof == 1 ? c.sdof[0] : (ndof == 2 ? c.sdof[1] : c.sdof[2]);
@@ -859,7 +859,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     const int sc = __builtin_amdgcn_readfirstlane(self_collide(c.T, (ModelPtr)c.M, lane, c.nc));  // wave-uniform by construction
 #endif
     c.nsc = sc & 0xff;
-    if (sc >> 8) c.overflow = 1;
+    if (sc >> 8) c.overflow |= 1;
     for (int k = c.nc; k < c.nc + c.nsc; k++) c.nact += T.c_excl[k] ? 0 : 1;
   }
   DM_SYNC();
@@ -1329,7 +1329,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       }
       R += __popcll(bal);
     }
-    if (R > RMAX) { R = RMAX; c.overflow = 1; }
+    if (R > RMAX) { R = RMAX; c.overflow |= 2; }
   }
   const bool constrained = R > 0;
   int iters = 0;
@@ -1368,7 +1368,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mycol = max(mycol, __shfl_xor(mycol, off));
-    if (mycol > 12) c.overflow = 1;  // more than 12 rows in one block of M (e.g. five ball contacts on one leg): the extra rows are
+    if (mycol > 12) c.overflow |= 4;  // more than 12 rows in one block of M (e.g. five ball contacts on one leg): the extra rows are
                                      // dropped and the env is flagged (wave-uniform here: lane 0 reports it)
     ncol = min(mycol, 12);
   }
@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     // key of the next launch's order: what a wave's lifetime varies with - Newton iterations over the step's substeps (4 us each)
     // and the number of contacts (40 us each; least-squares fit of the lifetimes in tools/wave_timeline.py's trace)
     cost[env] = min(255, iters + 10 * (c.nc + c.nsc));
-    if (do_reset) S.overflow = 0; else if (c.overflow) S.overflow = 1;
+    if (do_reset) S.overflow = 0; else S.overflow |= c.overflow;  // sticky over the episode: 1 contacts > 10, 2 constraint rows > 32, 4 rows of one block > 12
     S.have_ws = do_reset ? 0 : c.have_ws;
   }
 #ifdef FFB_STAMPS

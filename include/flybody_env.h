@@ -146,7 +146,8 @@ int ffe_get_state(ffe_handle h, double *qpos_dev, double *qvel_dev, void *stream
 int ffe_set_state(ffe_handle h, const double *qpos_dev, const double *qvel_dev, void *stream);
 /* task-side state per env: {wbpg_step, wbpg_freq_idx, step_counter, traj_idx, needs_reset, n_active_limits,
  * solver_iters, reserved} int32[B][8] and {wbpg_ctrl_freq, ghost_pos[3], ghost_quat[4]} float64[B][8].
- * walk_on_ball handles: {contact history lo, hi, step_counter, 0, needs_reset, contacts, solver_iters, overflow} - the
+ * walk_on_ball handles: {contact history lo, hi, step_counter, 0, needs_reset, contacts, solver_iters, overflow (sticky over
+ * the episode; bit 0 more than 10 contacts, bit 1 more than 32 constraint rows, bit 2 more than 12 rows in one block of M)} - the
  * contact history holds, 4 bits per substep for the first 16 substeps of the last control step, the number of contacts
  * inside their includemargin (the ones that received constraint rows); reals are zero */
 int ffe_get_task_state(ffe_handle h, int32_t *ints_dev, double *reals_dev, void *stream);
