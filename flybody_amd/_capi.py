@@ -14,7 +14,7 @@ SYMBOLS = [
     "ffe_physics_step", "ffe_force_next_episode", "ffe_get_state", "ffe_set_state", "ffe_get_task_state", "ffe_time_steps", "ffe_time_kernel",
     "ffe_test_quat", "ffe_last_error", "ffe_version", "ffe_create_walk_on_ball", "ffe_get_act", "ffe_set_act",
     "ffe_nstep_create", "ffe_nstep_observe", "ffe_nstep_buffers", "ffe_nstep_destroy", "ffe_nstep_last_error",
-    "ffe_pack_timestep",
+    "ffe_pack_timestep", "ffe_episode_stats",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
     L.ffe_nstep_destroy.argtypes = [vp]
     L.ffe_pack_timestep.argtypes = [fp, fp, fp, ip, fp, C.c_int, C.c_int, vp]
     L.ffe_pack_timestep.restype = C.c_int
+    L.ffe_episode_stats.argtypes = [ip, fp, fp, vp, vp, vp, C.c_int, vp]
+    L.ffe_episode_stats.restype = C.c_int
     L.ffe_nstep_last_error.restype = C.c_char_p
     L.ffe_nstep_last_error.argtypes = [vp]
     for s in ("ffe_nstep_create", "ffe_nstep_observe", "ffe_nstep_buffers", "ffe_nstep_destroy"):

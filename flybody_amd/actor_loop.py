@@ -104,38 +104,66 @@ class BatchedActorLoop:
         B, dev = env.batch_size, env.device
         self._ret = torch.zeros(B, device=dev)
         self._len = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.finished_returns, self.finished_lengths = [], []
+        # episode statistics accumulate on the device: nothing in the loop reads a value back, so launches stay queued ahead
+        self._tot = torch.zeros(2, dtype=torch.int64, device=dev)  # finished episodes, sum of their lengths
+        self._sum_ret = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._L = _capi.lib()
 
     @property
     def episodes(self) -> int:
-        return sum(len(x) for x in self.finished_returns)
+        return int(self._tot[0].item())
 
-    def run(self, num_steps: int) -> dict:
-        """Steps every env `num_steps` times (episodes roll over through the env's auto-reset)."""
+    def _iteration(self):
+        t = self._t
+        with t.no_grad():
+            action = self.policy(self.env.flat_observation)
+        action = action.contiguous()
+        ts = self.env.step(action)
+        if self.adder is not None:
+            self.adder.observe(action, ts, self.env.flat_observation)
+        # per-env return / length and the totals of finished episodes: one fused launch (ffe_episode_stats)
+        rc = self._L.ffe_episode_stats(ts.step_type.data_ptr(), ts.reward.data_ptr(), self._ret.data_ptr(), self._len.data_ptr(), self._tot.data_ptr(),
+                                       self._sum_ret.data_ptr(), self.env.batch_size, C.c_void_p(t.cuda.current_stream(self.env.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("ffe_episode_stats failed")
+
+    def run(self, num_steps: int, graph: bool = False) -> dict:
+        """Steps every env `num_steps` times (episodes roll over through the env's auto-reset).  With `graph` one iteration
+        (policy, env step, adder, statistics) is captured once into a HIP graph and replayed, which takes the host out of the
+        loop (measured neutral with the reference-shaped policy at B = 8192, where the GPU is the bound: tools/bench_actor_loop.py;
+        it matters for small batches).  Needs a policy whose work is all on the
+        env's device and free of host synchronisation; the env must not be double-buffered."""
         t = self._t
         ts = self.env.reset()
-        self._ret.zero_(); self._len.zero_()
+        self._ret.zero_(); self._len.zero_(); self._tot.zero_(); self._sum_ret.zero_()
         if self.adder is not None:
             self.adder.observe(t.zeros(self.env.batch_size, self.adder.act_dim, device=self.env.device), ts, self.env.flat_observation)
+        if graph:
+            side = t.cuda.Stream(self.env.device)
+            side.wait_stream(t.cuda.current_stream(self.env.device))
+            with t.cuda.stream(side):
+                for _ in range(3):
+                    self._iteration()
+            t.cuda.current_stream(self.env.device).wait_stream(side)
+            g = t.cuda.CUDAGraph()
+            with t.cuda.graph(g):
+                self._iteration()
+            t.cuda.synchronize(self.env.device)
+            start = time.perf_counter()
+            for _ in range(num_steps):
+                g.replay()
+            t.cuda.synchronize(self.env.device)
+            wall = time.perf_counter() - start
+            n = int(self._tot[0].item())
+            return {"episodes": n, "episode_return": float(self._sum_ret.item()) / n if n else float("nan"),
+                    "episode_length": float(self._tot[1].item()) / n if n else float("nan"),
+                    "steps_per_second": num_steps * self.env.batch_size / wall}
         start = time.perf_counter()
         for _ in range(num_steps):
-            with t.no_grad():
-                action = self.policy(self.env.flat_observation)
-            action = action.contiguous()
-            ts = self.env.step(action)
-            if self.adder is not None:
-                self.adder.observe(action, ts, self.env.flat_observation)
-            mid_or_last = ts.step_type != 0
-            self._ret += t.where(mid_or_last, ts.reward, t.zeros_like(ts.reward))
-            self._len += mid_or_last.to(t.int64)
-            done = ts.step_type == 2
-            if bool(done.any()):
-                self.finished_returns.append(self._ret[done].clone()); self.finished_lengths.append(self._len[done].clone())
-                self._ret[done] = 0; self._len[done] = 0
+            self._iteration()
         t.cuda.synchronize(self.env.device)
         wall = time.perf_counter() - start
-        rets = t.cat(self.finished_returns) if self.finished_returns else t.zeros(0, device=self.env.device)
-        lens = t.cat(self.finished_lengths) if self.finished_lengths else t.zeros(0, dtype=t.int64, device=self.env.device)
-        return {"episodes": int(rets.numel()), "episode_return": float(rets.mean()) if rets.numel() else float("nan"),
-                "episode_length": float(lens.float().mean()) if lens.numel() else float("nan"),
+        n = int(self._tot[0].item())
+        return {"episodes": n, "episode_return": float(self._sum_ret.item()) / n if n else float("nan"),
+                "episode_length": float(self._tot[1].item()) / n if n else float("nan"),
                 "steps_per_second": num_steps * self.env.batch_size / wall}

@@ -37,21 +37,25 @@ struct Dev {
   unsigned long long *written;            // transitions written so far (monotone)
 };
 
-// writes the transition that starts at ring entry `s` (0 = oldest of `len` entries), spanning entries s .. len-1
-__device__ __forceinline__ void emit(const Dev &D, int env, int lane, int first, int s, int len, const float *next_obs, unsigned long long slot) {
+// writes the transition that starts at ring entry `s` (0 = oldest of `len` entries), spanning entries s .. len-1.
+// `rew_l` / `disc_l`: lane i holds the reward / discount of the i-th oldest entry (n_step <= 64), else they are read from the ring.
+__device__ __forceinline__ void emit(const Dev &D, int env, int lane, int first, int s, int len, const float *next_obs, unsigned long long slot,
+                                     float rew_l, float disc_l, bool in_lanes) {
   const int n = D.n_step, O = D.obs_dim, A = D.act_dim;
   const float *rr = D.r_rew + (size_t)env * n, *rd = D.r_disc + (size_t)env * n;
-  // serial over <= n terms in lane 0's order would be simplest; keep acme's order of operations (left to right) so the
-  // float32 result matches a scalar restatement bit for bit
+  // acme's order of operations (left to right) is kept so that the float32 result matches a scalar restatement bit for bit; the
+  // chain runs wave-uniformly on values broadcast from the lanes (no memory access inside the dependent chain)
   float ret = 0.f, td = 1.f;
-  if (lane == 0) {
+  {
 #pragma clang fp contract(off)
     for (int i = s; i < len; i++) {
-      const int e = (first + i) % n;
-      if (i == s) { ret = rr[e]; td = rd[e]; }
-      else { td *= D.gamma; ret += rr[e] * td; td *= rd[e]; }
+      float r_, d_;
+      if (in_lanes) { r_ = __shfl(rew_l, i); d_ = __shfl(disc_l, i); }
+      else { const int e = (first + i) % n; r_ = rr[e]; d_ = rd[e]; }
+      if (i == s) { ret = r_; td = d_; }
+      else { td *= D.gamma; ret += r_ * td; td *= d_; }
     }
-    D.t_ret[slot] = ret; D.t_disc[slot] = td;
+    if (lane == 0) { D.t_ret[slot] = ret; D.t_disc[slot] = td; }
   }
   const int e0 = (first + s) % n;
   const float *so = D.r_obs + ((size_t)env * n + e0) * O, *sa = D.r_act + ((size_t)env * n + e0) * A;
@@ -59,48 +63,72 @@ __device__ __forceinline__ void emit(const Dev &D, int env, int lane, int first,
   for (int k = lane; k < A; k += 64) D.t_act[slot * A + k] = sa[k];
 }
 
-__global__ __launch_bounds__(64) void nstep_observe_kernel(Dev D, const float *__restrict__ action, const int *__restrict__ step_type,
-                                                           const float *__restrict__ reward, const float *__restrict__ discount,
-                                                           const float *__restrict__ obs) {
-  const int env = blockIdx.x, lane = threadIdx.x;
-  if (env >= D.batch) return;
+// kEnvsPerBlock envs per workgroup, one wavefront each.  The slots of the replay ring are claimed with ONE atomic per workgroup
+// (the waves' counts are summed through LDS): a device-scope atomic on a single address is served by the memory side, one after
+// the other across all eight XCDs, and one per env (8 192 per call) cost more than everything else in this kernel together.
+constexpr int kEnvsPerBlock = 16;
+__global__ __launch_bounds__(64 * kEnvsPerBlock) void nstep_observe_kernel(Dev D, const float *__restrict__ action, const int *__restrict__ step_type,
+                                                                           const float *__restrict__ reward, const float *__restrict__ discount,
+                                                                           const float *__restrict__ obs) {
+  __shared__ int s_total[kEnvsPerBlock];
+  __shared__ unsigned long long s_base;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = blockIdx.x * kEnvsPerBlock + wave;
+  const bool live = env < D.batch;
   const int n = D.n_step, O = D.obs_dim, A = D.act_dim;
-  const float *o_next = obs + (size_t)env * O;
-  float *lo = D.last_obs + (size_t)env * O;
-  const int st = step_type[env];
-  if (st == FFE_STEP_FIRST) {  // observe_first: new episode
+  const float *o_next = obs + (size_t)(live ? env : 0) * O;
+  float *lo = D.last_obs + (size_t)(live ? env : 0) * O;
+  const int st = live ? step_type[env] : FFE_STEP_FIRST;
+  const bool first_step = st == FFE_STEP_FIRST;
+  int head = 0, cnt = 0, head_new = 0, cnt_new = 0, first = 0, total = 0;
+  if (live && !first_step) {
+    head = D.head[env]; cnt = D.count[env];
+    head_new = (head + 1) % n; cnt_new = cnt < n ? cnt + 1 : n;
+    first = (head_new - cnt_new + n) % n;  // ring index of the oldest held entry after this append
+    // how many transitions this call writes: the full-length one (if n entries are held) and, on LAST, every shorter tail
+    const int n_full = cnt_new == n ? 1 : 0;
+    total = n_full + (st == FFE_STEP_LAST ? cnt_new - n_full : 0);
+  }
+  if (lane == 0) s_total[wave] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sum = 0;
+    for (int w = 0; w < kEnvsPerBlock; w++) sum += s_total[w];
+    s_base = sum > 0 ? atomicAdd(D.written, (unsigned long long)sum) : 0ull;
+  }
+  // (the atomic's round trip overlaps the loads and row copies below; the base is read after the next barrier)
+  // rewards / discounts of the held entries, one per lane (the entry appended by this call comes from the arguments)
+  const bool in_lanes = n <= 64;
+  float rew_l = 0.f, disc_l = 0.f;
+  if (live && !first_step) {
+    if (in_lanes && lane < cnt_new) {
+      const int e = (first + lane) % n;
+      if (e == head) { rew_l = reward[env]; disc_l = discount[env]; }
+      else { rew_l = D.r_rew[(size_t)env * n + e]; disc_l = D.r_disc[(size_t)env * n + e]; }
+    }
+    // append (o_t, a_t, r_{t+1}, d_{t+1}); when the ring is full its oldest entry (already written out) is overwritten
+    float *ro = D.r_obs + ((size_t)env * n + head) * O, *ra = D.r_act + ((size_t)env * n + head) * A;
+    for (int k = lane; k < O; k += 64) ro[k] = lo[k];
+    for (int k = lane; k < A; k += 64) ra[k] = action[(size_t)env * A + k];
+    if (lane == 0) { D.r_rew[(size_t)env * n + head] = reward[env]; D.r_disc[(size_t)env * n + head] = discount[env]; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (!live) return;
+  if (first_step) {  // observe_first: new episode
     for (int k = lane; k < O; k += 64) lo[k] = o_next[k];
     if (lane == 0) { D.head[env] = 0; D.count[env] = 0; }
     return;
   }
-  int head = D.head[env], cnt = D.count[env];
-  // append (o_t, a_t, r_{t+1}, d_{t+1}); when the ring is full its oldest entry (already written out) is overwritten
-  float *ro = D.r_obs + ((size_t)env * n + head) * O, *ra = D.r_act + ((size_t)env * n + head) * A;
-  for (int k = lane; k < O; k += 64) ro[k] = lo[k];
-  for (int k = lane; k < A; k += 64) ra[k] = action[(size_t)env * A + k];
-  if (lane == 0) { D.r_rew[(size_t)env * n + head] = reward[env]; D.r_disc[(size_t)env * n + head] = discount[env]; }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  head = (head + 1) % n;
-  cnt = cnt < n ? cnt + 1 : n;
-  const int first = (head - cnt + n) % n;  // ring index of the oldest held entry
-  // how many transitions this call writes: the full-length one (if n entries are held) and, on LAST, every shorter tail
-  const int n_full = cnt == n ? 1 : 0;
-  const int n_tail = st == FFE_STEP_LAST ? cnt - n_full : 0;
-  const int total = n_full + n_tail;
-  unsigned long long base = 0;
   if (total > 0) {
-    if (lane == 0) base = atomicAdd(D.written, (unsigned long long)total);
-    base = __shfl(base, 0);
-    for (int j = 0; j < total; j++) {
-      // j = 0 is the oldest start; with a full ring that is the n-step transition, the rest (LAST only) start later
-      const int s = (n_full ? 0 : 0) + j;
-      emit(D, env, lane, first, s, cnt, o_next, (base + j) % (unsigned long long)D.capacity);
-    }
+    unsigned long long base = s_base;
+    for (int w = 0; w < wave; w++) base += (unsigned long long)s_total[w];
+    for (int j = 0; j < total; j++)  // j = 0 is the oldest start; with a full ring that is the n-step transition, the rest (LAST only) start later
+      emit(D, env, lane, first, j, cnt_new, o_next, (base + j) % (unsigned long long)D.capacity, rew_l, disc_l, in_lanes);
   }
   for (int k = lane; k < O; k += 64) lo[k] = o_next[k];
-  if (lane == 0) { D.head[env] = head; D.count[env] = cnt; }
+  if (lane == 0) { D.head[env] = head_new; D.count[env] = cnt_new; }
 }
 
 // one [B][O + 3] row per env: observation | reward | discount | step_type (as float): the unit the per-step gather moves
@@ -110,6 +138,32 @@ __global__ void pack_timestep_kernel(const float *__restrict__ obs, const float 
   if (i >= (long long)batch * w) return;
   const int env = (int)(i / w), k = (int)(i - (long long)env * w);
   out[i] = k < obs_dim ? obs[(long long)env * obs_dim + k] : (k == obs_dim ? rew[env] : (k == obs_dim + 1 ? disc[env] : (float)st[env]));
+}
+
+// per-env running episode return / length and batch totals of finished episodes, in one launch: the statistics the reference's
+// EnvironmentLoop logs (episode_return, episode_length; agents/ray_distributed_dmpo.py:401-440).  A FIRST row adds nothing; a LAST
+// row's episode is added to the totals {episodes, sum of lengths} (int64) and {sum of returns} (float64) and its counters restart.
+__global__ void episode_stats_kernel(const int *__restrict__ st, const float *__restrict__ rew, float *__restrict__ ep_ret, long long *__restrict__ ep_len,
+                                     long long *__restrict__ tot_i, double *__restrict__ tot_ret, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int done = 0;
+  long long len = 0;
+  double ret = 0.0;
+  if (i < batch) {
+    const int s = st[i];
+    float r = ep_ret[i];
+    long long l = ep_len[i];
+    if (s != FFE_STEP_FIRST) { r += rew[i]; l += 1; }
+    if (s == FFE_STEP_LAST) { done = 1; len = l; ret = (double)r; r = 0.f; l = 0; }
+    ep_ret[i] = r; ep_len[i] = l;
+  }
+  // wave totals by cross-lane sums, then one atomic per wave and quantity (LAST rows are rare)
+  for (int o = 32; o > 0; o >>= 1) { done += __shfl_xor(done, o); len += __shfl_xor(len, o); ret += __shfl_xor(ret, o); }
+  if ((threadIdx.x & 63) == 0 && done) {
+    atomicAdd((unsigned long long *)&tot_i[0], (unsigned long long)done);
+    atomicAdd((unsigned long long *)&tot_i[1], (unsigned long long)len);
+    atomicAdd(tot_ret, ret);
+  }
 }
 
 struct Handle {
@@ -186,7 +240,7 @@ int ffe_nstep_observe(ffe_nstep_handle p, const float *action_dev, const int32_t
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (prev != p->h.device) (void)hipSetDevice(p->h.device);
-  hipLaunchKernelGGL(ffn::nstep_observe_kernel, dim3(p->h.d.batch), dim3(64), 0, static_cast<hipStream_t>(stream), p->h.d, action_dev, step_type_dev,
+  hipLaunchKernelGGL(ffn::nstep_observe_kernel, dim3((p->h.d.batch + ffn::kEnvsPerBlock - 1) / ffn::kEnvsPerBlock), dim3(64 * ffn::kEnvsPerBlock), 0, static_cast<hipStream_t>(stream), p->h.d, action_dev, step_type_dev,
                      reward_dev, discount_dev, obs_dev);
   const hipError_t e = hipGetLastError();
   if (prev >= 0 && prev != p->h.device) (void)hipSetDevice(prev);
@@ -214,6 +268,14 @@ int ffe_pack_timestep(const float *obs_dev, const float *reward_dev, const float
   const long long total = (long long)batch * (obs_dim + 3);
   hipLaunchKernelGGL(ffn::pack_timestep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), obs_dev, reward_dev,
                      discount_dev, step_type_dev, packed_dev, batch, obs_dim);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int ffe_episode_stats(const int32_t *step_type_dev, const float *reward_dev, float *episode_return_dev, long long *episode_length_dev,
+                      long long *totals_i64_dev, double *total_return_dev, int batch, void *stream) {
+  if (!step_type_dev || !reward_dev || !episode_return_dev || !episode_length_dev || !totals_i64_dev || !total_return_dev || batch <= 0) return -1;
+  hipLaunchKernelGGL(ffn::episode_stats_kernel, dim3((batch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), step_type_dev, reward_dev,
+                     episode_return_dev, episode_length_dev, totals_i64_dev, total_return_dev, batch);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

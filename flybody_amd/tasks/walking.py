@@ -147,3 +147,29 @@ def synthetic_snippets(view: WalkModelView, n: int = 4, length: int = 200, dt: f
             r2s[i] = ft["root2site"]; jq[i] = ft["joint_quat"][1:]
         out.append({"qpos": qpos, "qvel": qvel, "root2site": r2s, "joint_quat": jq})
     return out
+
+
+def save_npz(path: str, snippets, joint_names, site_names, timestep_seconds: float = 2e-3):
+    """Ragged walking snippets in one file: rows concatenated + `traj_off`; names of the tracked joints / sites as the dataset
+    gives them (`trajectory_loaders.py:217-223`)."""
+    r = WalkRefSet(snippets)
+    np.savez_compressed(path, qpos=r.qpos, qvel=r.qvel, root2site=r.root2site, joint_quat=r.joint_quat, traj_off=r.off,
+                        joint_names=np.array(list(joint_names)), site_names=np.array(list(site_names)),
+                        timestep_seconds=np.float64(timestep_seconds))
+
+
+def load_npz(path: str):
+    """-> (WalkRefSet, joint_names, site_names, timestep_seconds)"""
+    z = np.load(path, allow_pickle=False)
+    off = z["traj_off"]
+    sn = [{k: z[k][off[i]:off[i + 1]] for k in ("qpos", "qvel", "root2site", "joint_quat")} for i in range(len(off) - 1)]
+    return WalkRefSet(sn), [str(x) for x in z["joint_names"]], [str(x) for x in z["site_names"]], float(z["timestep_seconds"])
+
+
+def inference_snippet(qpos7, qvel6):
+    """`InferenceWalkingTrajectoryLoader.set_next_trajectory` (`trajectory_loaders.py:226-254`): a root-only trajectory (qpos
+    [T, 7], qvel [T, 6]) for the task's inference mode, where the reward is the constant 1 and only the root preview is used."""
+    q, v = np.asarray(qpos7, dtype=np.float64), np.asarray(qvel6, dtype=np.float64)
+    assert q.ndim == 2 and q.shape[1] == 7 and v.shape == (len(q), 6)
+    T = len(q)
+    return {"qpos": q, "qvel": v, "root2site": np.zeros((T, 0, 3)), "joint_quat": np.zeros((T, 0, 4))}

@@ -191,6 +191,13 @@ int ffe_nstep_destroy(ffe_nstep_handle h);
  * step_type) of the current device into packed_dev[B][obs_dim + 3] (flybody_amd/distributed.py:TimestepGather). */
 int ffe_pack_timestep(const float *obs_dev, const float *reward_dev, const float *discount_dev, const int32_t *step_type_dev,
                       float *packed_dev, int batch, int obs_dim, void *stream);
+
+/* episode statistics of a batched actor loop, the ones the reference's EnvironmentLoop logs (agents/ray_distributed_dmpo.py:401-440:
+ * episode_return, episode_length): per env the running return [B] float32 and length [B] int64 (a FIRST row adds nothing), and for
+ * rows reporting LAST the batch totals {finished episodes, sum of their lengths} (int64[2]) and the sum of their returns (float64[1]);
+ * the finished env's counters restart.  One launch per step, nothing read back. */
+int ffe_episode_stats(const int32_t *step_type_dev, const float *reward_dev, float *episode_return_dev, long long *episode_length_dev,
+                      long long *totals_i64_dev, double *total_return_dev, int batch, void *stream);
 const char *ffe_nstep_last_error(ffe_nstep_handle h);
 
 #ifdef __cplusplus

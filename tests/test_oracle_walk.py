@@ -160,3 +160,39 @@ def test_episode_protocol(view, refs):
     a = np.zeros(e3.naction); a[5] = np.nan
     st, r, d, obs = e3.step(a)
     assert np.isfinite(obs).all() and np.isfinite(r)
+
+
+def test_walking_dataset_converter_and_npz_round_trip(tmp_path, view):
+    """tools/convert_hdf5_to_npz.py --walking (h5py is absent: its layout logic is driven with an in-memory stand-in): lengths from
+    `trajectory_lengths`, root x / y re-based, short snippets dropped; the npz round-trips into the set the oracle takes."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import convert_hdf5_to_npz as conv
+
+    rng = np.random.RandomState(3)
+    J, S = len(view.mocap_jnt), len(view.mocap_site)
+    lens, store = [80, 40, 120], []
+    for L in lens:
+        T = L + 7  # stored arrays are longer than the valid length
+        store.append({"root_qpos": rng.randn(T, 7), "qpos": rng.randn(T, J), "root_qvel": rng.randn(T, 6), "qvel": rng.randn(T, J),
+                      "root2site": rng.randn(T, S, 3), "joint_quat": rng.randn(T, J, 4)})
+    dst = str(tmp_path / "walk.npz")
+    n, lo, hi = conv.convert_walking(lambda i: store[i], 3, lens, view.meta["mocap_joints"], view.meta["mocap_sites"], dst)
+    assert (n, lo, hi) == (2, 80, 120)  # the 40-row snippet cannot hold an episode (needs 66 rows)
+    refs, jn, sn, dt = W.load_npz(dst)
+    assert refs.ntraj == 2 and list(refs.off) == [0, 80, 200] and jn == view.meta["mocap_joints"] and sn == view.meta["mocap_sites"] and dt == 2e-3
+    a = refs.snippet(1)
+    assert np.allclose(a["qpos"][:, 2:7], store[2]["root_qpos"][:120, 2:]) and np.allclose(a["qpos"][:, 7:], store[2]["qpos"][:120])
+    assert np.allclose(a["qpos"][0, :2], 0.0) and np.allclose(a["qpos"][5, :2], store[2]["root_qpos"][5, :2] - store[2]["root_qpos"][0, :2])
+    assert np.allclose(a["joint_quat"], store[2]["joint_quat"][:120]) and np.allclose(a["root2site"], store[2]["root2site"][:120])
+    # inference mode: a root-only trajectory, constant reward (walk_imitation.py:148-151)
+    T = 90
+    q = np.zeros((T, 7)); q[:, 2] = view.m.qpos0[2]; q[:, 3] = 1.0; q[:, 0] = 0.002 * np.arange(T)
+    snip = W.inference_snippet(q, np.zeros((T, 6)))
+    m = O.OracleModel(BLOB)
+    e = O.OracleWalkEnv(m, W.WalkRefSet([snip]), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), (view.retract_qadr, view.retract_val),
+                        inference_mode=True)
+    e.reset()
+    st, r, d, obs = e.step(np.zeros(e.naction))
+    assert st == 1 and r == 1.0 and d == 1.0

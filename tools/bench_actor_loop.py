@@ -1,0 +1,52 @@
+"""End-to-end actor throughput on one GPU: env.step + policy network + n-step transition writer, all device-resident
+(`flybody_amd/actor_loop.py`; what the reference does with one OS process per env: agents/ray_distributed_dmpo.py:401-440,514-521).
+The policy is the reference's DMPO policy shape (LayerNormMLP 512-512-256 + a diagonal Gaussian head, train_dmpo_ray.py),
+random weights, sampled actions in the canonical [-1, 1] spec (clipped).    python tools/bench_actor_loop.py [steps]"""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from flybody_amd.actor_loop import BatchedActorLoop, NStepTransitionWriter
+from flybody_amd.batched_env import BatchedFlyEnv
+from flybody_amd.tasks.synthetic import base_wing_pattern, flight_trajectories
+from flybody_amd.tasks.trajectories import preprocess
+from flybody_amd.tasks.wbpg import build_tables
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+B = 8192
+tables = build_tables(base_wing_pattern()); rq, rv = preprocess(*flight_trajectories(64, 3006))
+
+
+class Policy(torch.nn.Module):
+    def __init__(self, obs, act):
+        super().__init__()
+        self.l0 = torch.nn.Linear(obs, 512); self.ln = torch.nn.LayerNorm(512)
+        self.l1 = torch.nn.Linear(512, 512); self.l2 = torch.nn.Linear(512, 256)
+        self.mean = torch.nn.Linear(256, act); self.std = torch.nn.Linear(256, act)
+
+    def forward(self, o):
+        h = torch.tanh(self.ln(self.l0(o)))
+        h = torch.nn.functional.elu(self.l1(h)); h = torch.nn.functional.elu(self.l2(h))
+        mu, sd = self.mean(h), torch.nn.functional.softplus(self.std(h)) + 1e-4
+        return torch.clamp(mu + sd * torch.randn_like(mu), -1.0, 1.0)
+
+
+torch.manual_seed(0)
+out = {}
+for name in ("env_only_fixed_action", "env_plus_policy", "env_plus_policy_plus_nstep_writer"):
+    env = BatchedFlyEnv(tables, rq, rv, batch_size=B, seed=0, canonical_actions=True, clip_actions=True)
+    pol = Policy(env.spec.obs_dim, env.spec.action_dim).cuda()
+    fixed = (torch.rand(B, env.spec.action_dim, device="cuda") * 2 - 1).contiguous()
+    policy = (lambda o: fixed) if name == "env_only_fixed_action" else pol
+    adder = NStepTransitionWriter(B, env.spec.obs_dim, env.spec.action_dim, n_step=50, discount=0.99, capacity=1 << 20) if name.endswith("writer") else None
+    loop = BatchedActorLoop(env, policy, adder)
+    loop.run(30)
+    r = loop.run(steps)
+    out[name] = {"env_steps_per_s": round(r["steps_per_second"], 1), "ms_per_step": round(1e3 * B / r["steps_per_second"], 4), "episodes": r["episodes"],
+                 "mean_episode_length": round(r["episode_length"], 1)}
+    rg = loop.run(steps, graph=True)  # the same iteration captured once into a HIP graph and replayed
+    out[name]["hip_graph"] = {"env_steps_per_s": round(rg["steps_per_second"], 1), "ms_per_step": round(1e3 * B / rg["steps_per_second"], 4),
+                              "episodes": rg["episodes"]}
+    if adder is not None:
+        out[name]["transitions_written"] = adder.num_written(); adder.close()
+    env.close()
+print(json.dumps(out))

@@ -37,14 +37,52 @@ def convert(read_group, keys, dt, dst, min_len=8):
     return len(keep), min(lens), max(lens)
 
 
+def convert_walking(read_snippet, n, lengths, joint_names, site_names, dst, dt=2e-3, min_len=66):
+    """The walking dataset (`trajectory_loaders.py:135-223`): per snippet `root_qpos (T,7)`, `qpos (T,J)`, `root_qvel (T,6)`,
+    `qvel (T,J)`, `root2site (T,S,3)`, `joint_quat (T,J,4)`, cut to `trajectory_lengths[i]` rows, x / y of the root re-based to the
+    first row (`trajectory_loaders.py:206`).  `read_snippet(i) -> dict` of those arrays; kept apart from h5py for testing.  An
+    episode needs future_steps + 2 = 66 rows (`walk_imitation.py:99-100`): shorter snippets are dropped."""
+    import numpy as np
+
+    from flybody_amd.tasks.walking import save_npz
+
+    out, keep = [], []
+    for i in range(n):
+        g, L = read_snippet(i), int(lengths[i])
+        if L < min_len:
+            continue
+        qpos = np.concatenate((np.asarray(g["root_qpos"], dtype=np.float64)[:L], np.asarray(g["qpos"], dtype=np.float64)[:L]), axis=1)
+        qvel = np.concatenate((np.asarray(g["root_qvel"], dtype=np.float64)[:L], np.asarray(g["qvel"], dtype=np.float64)[:L]), axis=1)
+        qpos[:, :2] -= qpos[0, :2]
+        out.append({"qpos": qpos, "qvel": qvel, "root2site": np.asarray(g["root2site"], dtype=np.float64)[:L],
+                    "joint_quat": np.asarray(g["joint_quat"], dtype=np.float64)[:L]})
+        keep.append(i)
+    if not out:
+        raise SystemExit("no snippet is long enough")
+    save_npz(dst, out, joint_names, site_names, dt)
+    return len(keep), min(len(s["qpos"]) for s in out), max(len(s["qpos"]) for s in out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("dst")
+    ap.add_argument("--walking", action="store_true", help="the source is the walking imitation dataset (snippets with tracked joints and sites)")
     ap.add_argument("--min-len", type=int, default=8, help="drop trajectories shorter than this many steps (future_steps + 2 is the minimum an episode needs)")
     args = ap.parse_args()
     import h5py  # noqa: deferred, not installed in the build image
 
+    if args.walking:
+        with h5py.File(args.src, "r") as f:
+            lens = f["trajectory_lengths"][()]
+            n = len(lens)
+            nz = len(str(n))
+            jn = [s.decode("utf-8") for s in f["id2name"]["joints"]]
+            sn = [s.decode("utf-8") for s in f["id2name"]["sites"]]
+            rd = lambda i: {k: f["trajectories"][str(i).zfill(nz)][k][()] for k in ("root_qpos", "qpos", "root_qvel", "qvel", "root2site", "joint_quat")}
+            n_kept, lo, hi = convert_walking(rd, n, lens, jn, sn, args.dst, min_len=max(args.min_len, 66))
+        print(f"wrote {args.dst}: {n_kept} snippets, {lo}..{hi} rows")
+        return
     with h5py.File(args.src, "r") as f:
         dt = float(f["timestep_seconds"][()])
         n = len(f["trajectories"])
