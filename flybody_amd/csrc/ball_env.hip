@@ -808,11 +808,23 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     if (cd >= 1e-15f) nrm = frcp(cd) * dif;
     cpos = bc + (M.b_radius + 0.5f * dist) * nrm;
   }
-  const unsigned long long bal = __ballot(hit);
+  unsigned long long bal = __ballot(hit);
+  if (__popcll(bal) > NC) {
+    // more contacts than the tile holds: the env is flagged and the NC DEEPEST are kept (dropping a deep one lets the leg sink in
+    // until a later substep answers with an enormous force: tools/soak.py saw such envs blow up at saturated actions)
+    c.overflow |= 1;
+    int rank = 0;
+    for (unsigned long long m = bal; m; m &= m - 1) {
+      const int j = __ffsll((long long)m) - 1;
+      const float dj = __shfl(dist, j);
+      if (dj < dist || (dj == dist && j < lane)) rank++;
+    }
+    hit = hit && rank < NC;
+    bal = __ballot(hit);
+  }
   const int idx = __popcll(bal & ((1ull << lane) - 1ull));
   c.nc = min(__popcll(bal), NC);
   c.nact = __popcll(__ballot(hit && idx < NC && !(dist >= margin - gap)));
-  if (__popcll(bal) > NC) c.overflow |= 1;  // more contacts than the tile holds: the extra ones are dropped and the env is flagged
   if (hit && idx < NC) {
     T.c_link[idx] = lane;
     const int last = ndof == 1 ? c.sdof[0] : (ndof == 2 ? c.sdof[1] : c.sdof[2]);
@@ -1368,9 +1380,17 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mycol = max(mycol, __shfl_xor(mycol, off));
-    if (mycol > 12) c.overflow |= 4;  // more than 12 rows in one block of M (e.g. five ball contacts on one leg): the extra rows are
-                                     // dropped and the env is flagged (wave-uniform here: lane 0 reports it)
+    if (mycol > 12) c.overflow |= 4;  // more than 12 rows in one block of M (e.g. five ball contacts on one leg): the env is flagged
+                                     // (wave-uniform here: lane 0 reports it) and the rows without a column exert no force (below)
     ncol = min(mycol, 12);
+    if (mycol > 12) {
+      // A row without a column would keep its force law but lose its own response (its row of G stays empty): an explicit spring
+      // of stiffness D - the blow-ups tools/soak.py saw at saturated actions.  Such rows are switched off for this substep
+      // instead: a contact as a whole (all three rows), a limit or fly-fly row through D = 0.
+      DM_SYNC();
+      const bool nocol = lane < R && ((int)T.r_col[lane] >= 12 || (myb2 >= 0 && mycol2 >= 12));
+      if (nocol) { if (lane < nrc) T.c_excl[lane / 3] = 1; else T.r_D[lane] = 0.f; }
+    }
   }
   DM_SYNC();
   // G: ball coupling between contact rows, then the fly part M_blk^-1 from the block solves
