@@ -107,6 +107,27 @@ def test_one_substep_teacher_forced(torch_mod, flags, name):
     assert ev < 1.5e-4, name   # one substep of contact forces at float32 (measured 5e-5 with noslip, 3e-6 without)
 
 
+def test_one_substep_at_saturated_actions(torch_mod):
+    """The same comparison in the regime a random policy produces (every actuator driven over its whole range: several joints on
+    their limits, legs pressed into the ball).  States that exceed the kernel's row / contact capacities are flagged by the kernel,
+    must stay finite (rows without a solve column exert no force for that substep) and are excluded from the comparison."""
+    m, states = _oracle_states(32, 1.0, seed=9, settle=6)
+    rs = np.random.RandomState(21)
+    ctrls = [rs.uniform(-1.0, 1.0, 59).astype(np.float32) for _ in states]
+    ref = [_oracle_advance(m, s, c.astype(np.float64), 1) for s, c in zip(states, ctrls)]
+    q, v, a, ints = _gpu_advance(torch_mod, states, ctrls, 1)
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    ok = [i for i in range(len(states)) if ints[i, 7] == 0]
+    rows = [r[3][0][1] for r in ref]
+    print(f"saturated: {len(ok)} of {len(states)} states within capacity; oracle constraint rows min/mean/max {min(rows)}/{np.mean(rows):.1f}/{max(rows)}, "
+          f"contacts max {max(r[3][0][0] for r in ref)}")
+    assert len(ok) >= 24
+    eq = max(np.abs(q[i] - ref[i][0]).max() for i in ok)
+    ev = max(np.abs(v[i] - ref[i][1]).max() / max(1.0, np.abs(ref[i][1]).max()) for i in ok)
+    print(f"saturated: qpos {eq:.3e} qvel(rel) {ev:.3e}")
+    assert eq < 1e-6 and ev < 1.5e-4  # measured 2.2e-7 / 4.6e-5
+
+
 def test_ten_substeps_open_loop(torch_mod):
     m, states = _oracle_states(16, 0.4, seed=7)
     rs = np.random.RandomState(3)
