@@ -369,7 +369,9 @@ __device__ __forceinline__ float impedance(const float *si, float x) {
 __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane, const int nc) {
   BTile &T = *Tp;
   const BallModel FFE_GLOBAL &M = *Mp;
-  const float4 *pgc = reinterpret_cast<const float4 *>(&T.lk[0][0]), *pga = pgc + NPG;  // (centre, radius) and (axis, half length) per slot
+  // per slot: (centre, bounding radius), (axis, half length), radius
+  const float4 *pgc = reinterpret_cast<const float4 *>(&T.lk[0][0]), *pga = pgc + NPG;
+  const float *pgr = reinterpret_cast<const float *>(pgc + 2 * NPG);
   const float mclaw = M.sc_margin;
   const unsigned long long claws = M.sp_claw;
   const int sphere = M.sp_sphere;
@@ -377,7 +379,7 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
   const bool own = lane < NPG;
   const unsigned long long partners = own ? M.sp_mask[lane] : 0ull;
   const float4 o0 = own ? pgc[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float oreach = (own ? pga[lane].w : 0.f) + o0.w + (((claws >> lane) & 1ull) ? mclaw : 0.f);
+  const float oreach = o0.w + (((claws >> lane) & 1ull) ? mclaw : 0.f);
   unsigned near = 0u;  // bit t - 1: the pair (lane, lane + t) passed the bounding-sphere test
 #pragma unroll 4
   for (int t = 1; t <= NPG / 2; t++) {
@@ -385,9 +387,8 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
     j = j >= NPG ? j - NPG : j;
     if (own && ((partners >> j) & 1ull) && (t < NPG / 2 || lane < NPG / 2)) {
       const float4 p0 = pgc[j];
-      const float ph = pga[j].w;
       const float dx = p0.x - o0.x, dy = p0.y - o0.y, dz = p0.z - o0.z;
-      const float reach = oreach + ph + p0.w + mclaw;  // (the claw margin on both sides: a bound is all that is needed here)
+      const float reach = oreach + p0.w + mclaw;  // (the claw margin on both sides: a bound is all that is needed here)
       if (dx * dx + dy * dy + dz * dz <= reach * reach) near |= 1u << (t - 1);
     }
   }
@@ -408,7 +409,7 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
       s1 = swap ? j : lane; s2 = swap ? lane : j;
       const float4 ca = pgc[s1], aa = pga[s1], cb_ = pgc[s2], ab = pga[s2];
       const V3 p1 = {ca.x, ca.y, ca.z}, a1 = {aa.x, aa.y, aa.z}, p2 = {cb_.x, cb_.y, cb_.z}, a2 = {ab.x, ab.y, ab.z};
-      const float l1 = aa.w, r1 = ca.w, l2 = ab.w, r2 = cb_.w;
+      const float l1 = aa.w, r1 = pgr[s1], l2 = ab.w, r2 = pgr[s2];
       margin = (((claws >> s1) | (claws >> s2)) & 1ull) ? mclaw : 0.f;
       const V3 dif = p1 - p2;
       const float mb = -dot(a1, a2), u = -dot(a1, dif), v = dot(a2, dif), det = 1.f - mb * mb;
@@ -797,8 +798,9 @@ __device__ __forceinline__ void stage1(Ctx &c) {
       // two float4 arrays (centre | radius, axis | half length), slot-major: consecutive lanes read consecutive 16-byte words
       float4 *o = reinterpret_cast<float4 *>(&T.lk[0][0]);
       const int sl = M.g_slot[lane];
-      o[sl] = make_float4(gp.x, gp.y, gp.z, rad);
+      o[sl] = make_float4(gp.x, gp.y, gp.z, half + rad);  // bounding radius: all the broad phase reads of a partner
       o[NPG + sl] = make_float4(ax.x, ax.y, ax.z, half);
+      reinterpret_cast<float *>(o + 2 * NPG)[sl] = rad;
     }
     margin = M.g_margin[lane]; gap = M.g_gap[lane];
     const V3 dif = gp + x * ax - bc;
@@ -861,8 +863,9 @@ __device__ __forceinline__ void stage1(Ctx &c) {
       const V3 gc = c.xp + mv(xmat, V3{M.pg2_pos[0], M.pg2_pos[1], M.pg2_pos[2]});
       const V3 ga = mv(xmat, V3{M.pg2_axis[0], M.pg2_axis[1], M.pg2_axis[2]});
       float4 *o = reinterpret_cast<float4 *>(&T.lk[0][0]);
-      o[M.pg2_slot] = make_float4(gc.x, gc.y, gc.z, M.pg2_rad);
+      o[M.pg2_slot] = make_float4(gc.x, gc.y, gc.z, M.pg2_half + M.pg2_rad);
       o[NPG + M.pg2_slot] = make_float4(ga.x, ga.y, ga.z, M.pg2_half);
+      reinterpret_cast<float *>(o + 2 * NPG)[M.pg2_slot] = M.pg2_rad;
     }
     DM_SYNC();
 #ifdef FFB_SC_NOCALL
