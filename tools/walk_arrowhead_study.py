@@ -45,3 +45,20 @@ for k in range(20):
     G32 = (Gjj + Jh @ np.linalg.solve(S.astype(np.float64), Jh.T.astype(np.float64)).astype(f32)).astype(np.float64)
     worst["G_rel"] = max(worst["G_rel"], np.abs(G32 - G64).max() / np.abs(G64).max())
 print({k: float(v) for k, v in worst.items()})
+
+# ---- how many contacts / constraint rows the floor produces (sizes the kernel's contact slots and dense-solver variants)
+L = O.lib()
+for amp in (0.3, 1.0):
+    env = O.OracleWalkEnv(m, refs, view.mocap_jnt, view.mocap_site, (view.retract_qadr, view.retract_val), terminal_com_dist=float("inf"))
+    env.reset()
+    rng = np.random.RandomState(1)
+    ncon, nrow, nlim = [], [], []
+    for k in range(1500):
+        st, _, _, _ = env.step(rng.uniform(-amp, amp, env.naction))
+        d = env.data
+        d.forward()
+        t = np.ctypeslib.as_array(L.fo_efc_type(d.ptr), shape=(300,))[:d.nefc]
+        ncon.append(d.ncon); nrow.append(d.nefc); nlim.append(int((t == 0).sum()))
+    ncon, nrow, nlim = np.array(ncon), np.array(nrow), np.array(nlim)
+    print(f"floor, actions +-{amp}: contacts mean {ncon.mean():.1f} p99 {np.percentile(ncon, 99):.0f} max {ncon.max()}; constraint rows mean {nrow.mean():.1f} "
+          f"p99 {np.percentile(nrow, 99):.0f} max {nrow.max()}; limit rows mean {nlim.mean():.1f} max {nlim.max()}")
