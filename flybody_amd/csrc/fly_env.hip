@@ -415,6 +415,12 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   const int d_link = M.d_link[lane], d_kind = M.d_kind[lane];
   const unsigned anc_lo = M.l_anc[lane], anc_hi = M.l_anc[kLanePad + lane];  // ancestor links, nearest first, 0xff = none
   STAMP(8);  // everything between the last stamp and a stage 1 (integration, sensors, ghost, prologue)
+  // inertial constants of this lane's link, needed after the frame composition below: requested now, so that their L2 round
+  // trip runs under the kinematics instead of after its last hand-off
+  const int d_plink_ = M.l_parent[d_link], d_dof0_ = M.l_dofadr[d_link];  // (V3 below: parent link and first dof of this dof's link)
+  const float l_mass_ = M.l_mass[lane];
+  const V3 l_ipos_ = ldv_lane(M.l_ipos, lane), l_inertia_ = ldv_lane(M.l_inertia, lane);
+  const M3 l_imat_ = ldm_lane(M.l_imat, lane);
 
   // ---- K1: link frame in its parent (joint rotations folded in) + hinge axes in the final link frame
   if (is_link) {
@@ -480,9 +486,9 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     q = qnormalize(q);
     xp = p;
     xm = q2m(q);
-    mass = M.l_mass[lane];
-    xip = xp + mv(xm, ldv_lane(M.l_ipos, lane));
-    xim = mm(xm, ldm_lane(M.l_imat, lane));
+    mass = l_mass_;
+    xip = xp + mv(xm, l_ipos_);
+    xim = mm(xm, l_imat_);
     T.xpos[lane][0] = xp.x; T.xpos[lane][1] = xp.y; T.xpos[lane][2] = xp.z;
     float *xo = T.xmat[lane];
     xo[0] = xm.m0; xo[1] = xm.m1; xo[2] = xm.m2; xo[3] = xm.m3; xo[4] = xm.m4; xo[5] = xm.m5; xo[6] = xm.m6; xo[7] = xm.m7; xo[8] = xm.m8;
@@ -496,7 +502,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   }
   I10 cin = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (is_link) {
-    cin = inert_com(ldv_lane(M.l_inertia, lane), xim, xip - com1, mass);
+    cin = inert_com(l_inertia_, xim, xip - com1, mass);
     st10(T.cinert[lane], cin);
   }
   SYNC();
@@ -547,10 +553,8 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   S6 cdd = zero6();
   if (is_dof) {
     if (d_kind == 2) {
-      int b = d_link;
-      int pl = M.l_parent[b];
-      S6 cv = ld6(T.lb[pl]);
-      for (int e = M.l_dofadr[b]; e < lane; e++) cv = cv + T.qvel[e] * ld6(T.cdof[e]);
+      S6 cv = ld6(T.lb[d_plink_]);
+      for (int e = d_dof0_; e < lane; e++) cv = cv + T.qvel[e] * ld6(T.cdof[e]);
       cdd = cross_motion(cv, ld6(T.cdof[lane]));
     } else if (d_kind == 1) {
       S6 cv = {0.f, 0.f, 0.f, T.qvel[0], T.qvel[1], T.qvel[2]};  // free joint: after the 3 translations only
