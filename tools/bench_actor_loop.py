@@ -32,11 +32,18 @@ class Policy(torch.nn.Module):
 
 torch.manual_seed(0)
 out = {}
-for name in ("env_only_fixed_action", "env_plus_policy", "env_plus_policy_plus_nstep_writer"):
+for name in ("env_only_fixed_action", "env_plus_policy", "env_plus_policy_plus_nstep_writer", "env_plus_bf16_policy_plus_nstep_writer"):
     env = BatchedFlyEnv(tables, rq, rv, batch_size=B, seed=0, canonical_actions=True, clip_actions=True)
     pol = Policy(env.spec.obs_dim, env.spec.action_dim).cuda()
     fixed = (torch.rand(B, env.spec.action_dim, device="cuda") * 2 - 1).contiguous()
-    policy = (lambda o: fixed) if name == "env_only_fixed_action" else pol
+    if name == "env_only_fixed_action":
+        policy = lambda o: fixed
+    elif "bf16" in name:  # the same network under bf16 autocast (MFMA GEMMs); actions come back as float32
+        def policy(o, pol=pol):
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                return pol(o).float()
+    else:
+        policy = pol
     adder = NStepTransitionWriter(B, env.spec.obs_dim, env.spec.action_dim, n_step=50, discount=0.99, capacity=1 << 20) if name.endswith("writer") else None
     loop = BatchedActorLoop(env, policy, adder)
     loop.run(30)
