@@ -1705,6 +1705,11 @@ int ffe_action_bounds(ffe_handle h, float *mn, float *mx) {
   return 0;
 }
 
+// the ordering kernel pays for itself only while the launch is a couple of rounds of resident waves: +1.7 % at 8 192 envs,
+// -0.8 % at 16 384, -1.9 % at 32 768 (measured with the phase-aware key)
+#ifndef FFE_ORDER_MAX_BATCH
+#define FFE_ORDER_MAX_BATCH 8192
+#endif
 static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, float *disc, int32_t *st, void *stream, int mode, int nphys = 0,
                        const uint8_t *mask = nullptr) {
   if (!h) return -1;
@@ -1719,7 +1724,7 @@ static int launch_step(ffe_handle h, const float *act, float *obs, float *rew, f
   if (h->timing && hipEventRecord(h->ev1, static_cast<hipStream_t>(stream)) != hipSuccess) return -2;
   // measured: +2 % env-steps/s at B = 8 192 (two rounds of the 4 096 resident waves); beyond that the tail the order shortens
   // is a smaller share of the launch than the serialised sort kernel itself (-1.5 % at 16 384, -2 % at 32 768): not sorted
-  if (mode == 0 && h->batch > 1 && h->batch <= 8192 && !(h->task.flags & DBG_NO_ORDER)) {
+  if (mode == 0 && h->batch > 1 && h->batch <= FFE_ORDER_MAX_BATCH && !(h->task.flags & DBG_NO_ORDER)) {
     hipLaunchKernelGGL(ffe_order::order_by_cost, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), h->cost, h->order, h->batch);
     e = hipGetLastError();
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return -2; }
