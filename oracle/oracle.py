@@ -118,6 +118,15 @@ def lib():
         L.fo_self_min_clear.argtypes = [vp, ip, ip]
         L.fo_convex_separation.restype = C.c_double
         L.fo_convex_separation.argtypes = [vp, vp, C.c_int, C.c_int, dp]
+        L.fo_geom_sdf.restype = C.c_double
+        L.fo_geom_sdf.argtypes = [vp, vp, C.c_int, dp, dp, dp]
+        L.fo_convex_distance.restype = C.c_double
+        L.fo_convex_distance.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp]
+        L.fo_geom_support.argtypes = [vp, vp, C.c_int, dp, dp]
+        L.fo_geom_type.restype = ip
+        L.fo_geom_type.argtypes = [vp]
+        L.fo_geom_size.restype = dp
+        L.fo_geom_size.argtypes = [vp]
         L.fo_walk_env_new.restype = vp
         L.fo_walk_env_new.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, ip, C.c_int, ip, C.c_int, ip, dp, dp, dp, dp,
                                       C.c_double, C.c_int, ip, dp, C.c_uint64, C.c_uint64, C.c_int]

@@ -54,7 +54,9 @@ def test_quaternion_helpers_match_the_reference_goldens():
 def test_walk_model_dimensions(view):
     m = O.OracleModel(BLOB)
     assert (m.nq, m.nv, m.nu, m.na) == (109, 108, 59, 59)
-    assert m.npair == 1086 + 48  # the fly's own sphere / capsule pairs + the floor against every primitive geom
+    # the fly's own sphere / capsule pairs (1086) and its pairs with an ellipsoid or cylinder on one side (1202: the general convex
+    # collider) + the floor against every primitive geom; the floor against an ellipsoid / cylinder is not restated
+    assert m.npair == 1086 + 1202 + 48 and m.npair_unsupported == 22
     assert len(view.mocap_jnt) == 66 and len(view.mocap_site) == 6
 
 
@@ -118,7 +120,8 @@ def test_standing_fly_is_carried_by_the_floor(view, refs):
     d.forward()  # (a step ends on the position stage of the next one: solve the constraints at this state to read the forces)
     assert d.ncon >= 3
     cons = d.contacts()  # rows: geom1, geom2, dim, exclude, efc_adr, dist, pos[3], normal[3], mu, friction, includemargin, normal force
-    assert all(c[0] == 0 for c in cons)  # every contact is with the floor plane
+    cons = [c for c in cons if c[0] == 0]  # the contacts with the floor plane (the fly's own pairs are internal forces)
+    assert len(cons) >= 3
     assert all(np.allclose(c[9:12], [0, 0, 1]) for c in cons)  # normal = the plane's z axis, from the floor to the leg
     fz = sum(c[15] for c in cons)  # first row of a contact = its normal force
     from flybody_amd.model.blob import read_blob
