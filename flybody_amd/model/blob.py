@@ -131,6 +131,11 @@ def model_tensors(m, L=None, with_collision=False) -> dict:
             "touch_site": m.touch_site, "force_site": m.force_site, "appendage_site": np.array(app, dtype=np.int32),
             "solver_opt": np.array([m.cone_elliptic, m.noslip_iterations, m.impratio], dtype=np.float64),
         })
+        # static candidate list of the device kernels' broad phase (flybody_amd/model/reach.py)
+        from .reach import candidate_pairs
+        cand, _ = candidate_pairs(m)
+        t["cand_g1"] = np.array([c[0] for c in cand], dtype=np.int32)
+        t["cand_g2"] = np.array([c[1] for c in cand], dtype=np.int32)
     if L is None:
         return t
     t.update({
@@ -144,6 +149,8 @@ def model_tensors(m, L=None, with_collision=False) -> dict:
         "fell_link": L.fell_link, "fell_pos": L.fell_pos, "fell_mat": L.fell_mat,
         "fell_size": L.fell_size, "fell_coef": L.fell_coef,
     })
+    if with_collision:
+        t.update({"cgeom_link": L.cgeom_link, "cgeom_pos": L.cgeom_pos, "cgeom_quat": L.cgeom_quat})
     return t
 
 

@@ -1138,6 +1138,11 @@ def weld(m: CompiledModel) -> LinkModel:
     L.fell_mat = np.array(em).reshape(-1, 9)
     L.fell_size = m.fl_size.copy()
     L.fell_coef = m.fl_coef.copy()
+    # collision geoms in link coordinates (the flight kernel's contact stage; `tasks/base.py:299-302` leaves fly - fly collisions on)
+    ng = len(m.geom_bodyid)
+    L.cgeom_link = np.array([link_of_body[m.geom_bodyid[g]] for g in range(ng)], dtype=np.int32)
+    L.cgeom_pos = np.array([rel_pos[m.geom_bodyid[g]] + Q.rot(m.geom_pos[g], rel_quat[m.geom_bodyid[g]]) for g in range(ng)]).reshape(-1, 3)
+    L.cgeom_quat = np.array([Q.normalize(Q.mul(rel_quat[m.geom_bodyid[g]], m.geom_quat[g])) for g in range(ng)]).reshape(-1, 4)
     return L
 
 

@@ -49,7 +49,7 @@ def test_gravity_bias_is_potential_gradient(md):
     m, d = md
     _excite(m, d)
     q = d.qpos.copy()
-    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_DAMPER | O.FO_NO_SPRING)
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_CONTACT | O.FO_NO_DAMPER | O.FO_NO_SPRING)
     d.qvel[:] = 0
     d.forward()
     bias = d.qfrc_bias.copy()
@@ -76,9 +76,9 @@ def test_invariants_converge_first_order(md, quantity):
         m.timestep = h
         n = int(round(0.02 / h))
         if quantity == "energy":
-            m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_DAMPER | O.FO_NO_ACTUATION)
+            m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_CONTACT | O.FO_NO_DAMPER | O.FO_NO_ACTUATION)
         else:
-            m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_GRAVITY | O.FO_NO_ACTUATION)
+            m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_CONTACT | O.FO_NO_GRAVITY | O.FO_NO_ACTUATION)
         d2 = O.OracleData(m)
         _excite(m, d2)
         d2.forward()
@@ -96,7 +96,7 @@ def test_invariants_converge_first_order(md, quantity):
 
 def test_free_fall_reads_zero_proper_acceleration(md):
     m, d = md
-    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_ACTUATION | O.FO_NO_SPRING)
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_CONTACT | O.FO_NO_ACTUATION | O.FO_NO_SPRING)
     d.qvel[:] = 0
     d.forward()
     assert np.abs(d.sensors[6:9]).max() < 1e-9  # accelerometer
@@ -107,7 +107,7 @@ def test_free_fall_reads_zero_proper_acceleration(md):
 def test_accelerometer_of_held_fly_reads_g_along_world_z(md):
     """A fly whose root acceleration is exactly cancelled reads +981 along world-z in the thorax frame."""
     m, d = md
-    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_ACTUATION | O.FO_NO_SPRING | O.FO_NO_GRAVITY)
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_CONTACT | O.FO_NO_ACTUATION | O.FO_NO_SPRING | O.FO_NO_GRAVITY)
     th = np.deg2rad(47.5)
     d.qpos[3:7] = [np.cos(th / 2), 0, -np.sin(th / 2), 0]
     d.qvel[:] = 0
@@ -115,7 +115,7 @@ def test_accelerometer_of_held_fly_reads_g_along_world_z(md):
     assert np.abs(d.sensors[6:9]).max() < 1e-9
     # world acceleration +g of the frame is equivalent to gravity on with the fly held: use the relation
     # accelerometer = R^T (a - g) with a = 0  ->  R^T [0,0,981]
-    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_ACTUATION | O.FO_NO_SPRING)
+    m.set_flags(O.FO_NO_FLUID | O.FO_NO_LIMIT | O.FO_NO_CONTACT | O.FO_NO_ACTUATION | O.FO_NO_SPRING)
     d.forward()
     # subtract the free-fall acceleration the fly actually has (qacc root = -981 z, measured above)
     R = np.array([[np.cos(th), 0, -np.sin(th)], [0, 1, 0], [np.sin(th), 0, np.cos(th)]])
@@ -126,7 +126,7 @@ def test_accelerometer_of_held_fly_reads_g_along_world_z(md):
 def test_terminal_velocity_inertia_box_drag(md):
     """A non-rotating fly falling flat reaches the speed where the summed box drag equals its weight."""
     m, d = md
-    m.set_flags(O.FO_NO_LIMIT | O.FO_NO_ACTUATION)
+    m.set_flags(O.FO_NO_LIMIT | O.FO_NO_CONTACT | O.FO_NO_ACTUATION)
     d.qvel[:] = 0
     v_prev = 0.0
     for k in range(40000):

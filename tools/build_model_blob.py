@@ -19,9 +19,11 @@ OUT = os.path.join(os.path.dirname(__file__), "..", "flybody_amd", "assets")
 
 def main():
     m, L = build_flight_model()
-    write_blob(os.path.join(OUT, "fly_flight.ffmb"), model_tensors(m, L))
+    # with its collision geoms: the reference leaves fly - fly collisions on in flight (tasks/base.py:299-302 disables the floor only)
+    write_blob(os.path.join(OUT, "fly_flight.ffmb"), model_tensors(m, L, with_collision=True))
     meta = {
         "body_name": m.body_name,
+        "geom_name": m.geom_name,
         "jnt_name": m.jnt_name,
         "act_name": m.act_name,
         "ten_name": m.ten_name,
@@ -33,15 +35,11 @@ def main():
     with open(os.path.join(OUT, "fly_flight.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote", OUT, "nbody", m.nbody, "nv", m.nv, "nu", m.nu)
-    # The same flight model with its collision geoms attached: the product kernel carries no flight contacts (the floor is
-    # disabled, tasks/base.py:299-302); this blob lets the oracle measure how close the remaining fly-fly pairs come
-    # (tools/self_collision_stats.py).  Oracle-side asset only.
+    # the flight model WITHOUT its collision geoms: the oracle twin of `ffe_physics_step`'s contact-free BASELINE config 2 and of the
+    # known-answer physics tests (tests/test_oracle_physics.py)
     ocol = os.path.join(os.path.dirname(__file__), "..", "oracle", "assets")
     os.makedirs(ocol, exist_ok=True)
-    write_blob(os.path.join(ocol, "fly_flight_collision.ffmb"), model_tensors(m, L, with_collision=True))
-    with open(os.path.join(ocol, "fly_flight_collision.json"), "w") as f:
-        json.dump({"body_name": m.body_name, "geom_name": m.geom_name}, f, indent=1)
-    print("wrote flight collision blob: ngeom", len(m.geom_bodyid))
+    write_blob(os.path.join(ocol, "fly_flight_nocollision.ffmb"), model_tensors(m, L))
     b = build_ball_model()
     write_blob(os.path.join(OUT, "fly_ball.ffmb"), model_tensors(b, with_collision=True))
     meta = {

@@ -34,7 +34,7 @@ def _worker(args):
         from flybody_amd.tasks.trajectories import preprocess
         from flybody_amd.tasks.wbpg import build_tables
 
-        blob = os.path.join(ROOT, "oracle", "assets", "fly_flight_collision.ffmb")
+        blob = os.path.join(ROOT, "flybody_amd", "assets", "fly_flight.ffmb")
         names = json.load(open(blob.replace(".ffmb", ".json")))["geom_name"]
         m = O.OracleModel(blob)
         tables = build_tables(base_wing_pattern())
