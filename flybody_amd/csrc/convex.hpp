@@ -11,6 +11,8 @@
 // Hessian d H + g g' is bounded and regular), and n becomes the direction between them.  o(n) never increases; the fixed
 // point has the witness points facing each other along n.  One lane works on one pair, everything in registers.
 //
+// The pair classes that dominate the fly's contacts have cheaper exact formulations (further down: `prim_convex`, `ell_ell`,
+// `ell_cyl`); `collide` picks per pair.
 // The header also compiles for the host (-DCVX_HOST: tests/test_convex_f32_cpu.py runs this float32 code without a GPU);
 // the product includes it from the HIP kernels only.
 #pragma once
@@ -101,20 +103,30 @@ CVX_FN float sdf(const Geom &g, V3 x, V3 &grad, Sym3 &H) {
     grad = sz * a;  // cap: flat
     return dz;
   }
-  // ellipsoid: nearest surface point q_i = s_i^2 y_i / (s_i^2 + tau), tau the root of f = sum (s_i y_i / (s_i^2 + tau))^2 - 1 above
-  // -min s_i^2.  f is convex and decreasing there, so Newton from a point left of the root (f >= 0) climbs to it monotonically:
-  // tau_0 = max_i (s_i |y_i| - s_i^2) is such a point (its own term is 1, every term is <= 1, so 0 <= f <= 2), inside and outside.
+  // ellipsoid: nearest surface point q_i = s_i^2 y_i / (s_i^2 + tau), tau the root of F(tau) = sum (s_i y_i / (s_i^2 + tau))^2 = 1 above
+  // -min s_i^2, bracketed by lo = max_i (s_i |y_i| - s_i^2) (that term alone is 1 there) and hi = sqrt(sum s_i^2 y_i^2) - min s_i^2
+  // (every denominator is at least min s_i^2 + tau).  Newton on 1 / sqrt(F) - 1 - exactly linear in tau where one term dominates; plain
+  // Newton on F - 1 only gains a factor 1.5 per step next to a pole (a thin blade seen from its flat side) - kept inside the bracket,
+  // bisection when a step leaves it (the wing blades' three length scales make 1 / sqrt(F) rise, level off and rise again).
+  // 3 - 5 steps for the fly's rounder ellipsoids, up to 10 for the wing blades.
   const M3 R = q2m(g.q);
   const V3 y = mtv(R, v);
-  const float sx = g.s0 * g.s0, sy = g.s1 * g.s1, sz2 = g.s2 * g.s2;
+  const float sx = g.s0 * g.s0, sy = g.s1 * g.s1, sz2 = g.s2 * g.s2, smin = fminf(fminf(sx, sy), sz2);
   const float px = sx * y.x * y.x, py = sy * y.y * y.y, pz = sz2 * y.z * y.z;
-  float tau = fmaxf(fmaxf(g.s0 * fabsf(y.x) - sx, g.s1 * fabsf(y.y) - sy), g.s2 * fabsf(y.z) - sz2);
-#pragma unroll
-  for (int it = 0; it < 6; it++) {
+  float lo = fmaxf(fmaxf(g.s0 * fabsf(y.x) - sx, g.s1 * fabsf(y.y) - sy), g.s2 * fabsf(y.z) - sz2);
+  float hi = fmaxf(fsqrt(px + py + pz) - smin, lo);
+  float tau = lo;
+  bool done = false;
+#pragma unroll 1
+  for (int it = 0; it < 10 && !done; it++) {
     const float ax = frcp(sx + tau), ay = frcp(sy + tau), az = frcp(sz2 + tau);
     const float bx = px * ax * ax, by = py * ay * ay, bz = pz * az * az;
-    const float f = bx + by + bz - 1.f, df = -2.f * (bx * ax + by * ay + bz * az);
-    tau = (f > 0.f && df < 0.f) ? tau - f * frcp(df) : tau;
+    const float F = bx + by + bz, dF = -2.f * (bx * ax + by * ay + bz * az);
+    if (F > 1.f) lo = tau; else hi = tau;
+    float tn = dF < 0.f ? tau + 2.f * (F - F * fsqrt(F)) * frcp(dF) : hi;
+    if (!(tn >= lo && tn <= hi)) tn = 0.5f * (lo + hi);
+    done = fabsf(tn - tau) <= 2e-7f * (fabsf(tau) + smin) || hi - lo <= 2e-7f * (fabsf(tau) + smin);
+    tau = tn;
   }
   const float ax = frcp(sx + tau), ay = frcp(sy + tau), az = frcp(sz2 + tau);
   const V3 m = {y.x * ax, y.y * ay, y.z * az};
@@ -291,6 +303,318 @@ CVX_FN Result distance(Geom a, Geom b, V3 n, bool have_n, float sgap, float cull
   }
   r.pos = origin + 0.5f * (p1 + p2);
   return r;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pair classes with a cheaper exact formulation than the general iteration above.  Both solve the same minimum-translation
+// problem (same dist / normal / position as `distance`, to rounding) for contacts no deeper than the thinner geom's core.
+
+// (1) A capsule or sphere (geom1: lower type code) against an ellipsoid or cylinder: the capsule is its axis segment p + t a,
+// |t| <= half, swept by a ball of radius r, so dist = min over t of phi_G(p + t a) - r with phi_G the convex, C1 signed distance to
+// geom2: a one-dimensional convex minimisation, f'(t) = grad phi . a monotone.  Newton on f' inside a bracket.  A cylinder's
+// f' is only piecewise smooth - its curvature jumps by orders of magnitude where the axis point passes over the rim (|z| = H) or
+// over the side wall (rho = R) - so for a cylinder a Newton step never leaves the smooth piece it starts in: it stops just past
+// the piece's end (those breakpoints are roots of a linear and a quadratic equation in t) and continues there with the next
+// piece's curvature; f' being monotone, the walk crosses each breakpoint at most once.
+// Exact while the axis segment stays outside geom2 (phi > 0 at the minimiser: penetration shallower than the capsule's radius);
+// deeper, it returns the largest depth of an axis point, a lower bound of the true penetration (`shallow` = false).
+struct PResult { float dist; V3 n, pos; bool shallow; };
+template <int N_ITER>
+CVX_FN PResult prim_convex(Geom p, Geom g) {
+  const V3 origin = g.c;
+  p.c = p.c - g.c;
+  g.c = {0.f, 0.f, 0.f};
+  const V3 a = zaxis(p.q);
+  const float half = p.type == CAPSULE ? p.s1 : 0.f, r = p.s0;
+  // breakpoints of a cylinder's f' (ellipsoid: none)
+  float bk0 = 2.f * half + 1.f, bk1 = bk0, bk2 = bk0, bk3 = bk0;  // (beyond the segment = absent)
+  if (g.type == CYLINDER) {
+    const V3 ga = zaxis(g.q);
+    const float az = dot(a, ga), z0 = dot(p.c, ga);
+    if (fabsf(az) > 1e-6f) { const float iz = frcp(az); bk0 = (g.s1 - z0) * iz; bk1 = (-g.s1 - z0) * iz; }
+    const V3 ap = a - az * ga, pp = p.c - z0 * ga;
+    const float qa = dot(ap, ap), qb = dot(ap, pp), qc = dot(pp, pp) - g.s0 * g.s0, disc = qb * qb - qa * qc;
+    if (qa > 1e-12f && disc > 0.f) { const float sq = fsqrt(disc), iq = frcp(qa); bk2 = (-qb - sq) * iq; bk3 = (-qb + sq) * iq; }
+  }
+  const float nudge = 2e-6f * (half + r);
+  float lo = -half, hi = half;
+  bool lo_ev = false, hi_ev = false, conv = half == 0.f;
+  float t = fminf(fmaxf(-dot(a, p.c), lo), hi);
+  V3 grad = {1.f, 0.f, 0.f};
+  Sym3 H;
+  float f = 0.f;
+#pragma unroll 1
+  for (int it = 0; it < N_ITER && !conv; it++) {
+    const V3 x = p.c + t * a;
+    f = sdf<true>(g, x, grad, H);
+    const float d1 = dot(grad, a);
+    const float d2 = a.x * (H.xx * a.x + H.xy * a.y + H.xz * a.z) + a.y * (H.xy * a.x + H.yy * a.y + H.yz * a.z) + a.z * (H.xz * a.x + H.yz * a.y + H.zz * a.z);
+    const bool neg = d1 <= 0.f;  // the root lies at or beyond t
+    if (neg) { lo = t; lo_ev = true; } else { hi = t; hi_ev = true; }
+    // end of the smooth piece in the direction of the root
+    float pe;
+    if (neg) {
+      pe = hi;
+      if (bk0 > t + nudge && bk0 < pe) pe = bk0;
+      if (bk1 > t + nudge && bk1 < pe) pe = bk1;
+      if (bk2 > t + nudge && bk2 < pe) pe = bk2;
+      if (bk3 > t + nudge && bk3 < pe) pe = bk3;
+    } else {
+      pe = lo;
+      if (bk0 < t - nudge && bk0 > pe) pe = bk0;
+      if (bk1 < t - nudge && bk1 > pe) pe = bk1;
+      if (bk2 < t - nudge && bk2 > pe) pe = bk2;
+      if (bk3 < t - nudge && bk3 > pe) pe = bk3;
+    }
+    float tn = d2 > 1e-9f ? t - d1 * frcp(d2) : (neg ? pe + 1.f : pe - 1.f);
+    bool newton = true;
+    if (neg ? tn >= pe : tn <= pe) {  // the step leaves the piece: stop just past its end (a bracket end: on it, or bisect if evaluated)
+      newton = false;
+      const bool at_end = neg ? pe >= hi : pe <= lo;
+      tn = at_end ? ((neg ? hi_ev : lo_ev) ? 0.5f * (lo + hi) : pe) : (neg ? fminf(pe + nudge, hi) : fmaxf(pe - nudge, lo));
+    }
+    const float tol = 1e-7f * (half + r);
+    conv = fabsf(d1) <= 1e-7f || hi - lo <= tol || (newton && fabsf(tn - t) <= tol) || (neg && t >= half) || (!neg && t <= -half);
+    t = tn;
+  }
+  const V3 x = p.c + t * a;
+  f = sdf<false>(g, x, grad, H);
+  PResult out;
+  out.dist = f - r;
+  out.n = V3{-grad.x, -grad.y, -grad.z};
+  out.pos = origin + x - (0.5f * (r + f)) * grad;
+  out.shallow = f > 0.f;
+  return out;
+}
+
+// (2) Two ellipsoids: their support functions h_i(n) = sqrt(n' A_i n), A_i = R_i S_i^2 R_i', are smooth, so the overlap
+// o(n) = h_1(n) + h_2(n) - n . (c_2 - c_1) is minimised over the unit sphere directly: Newton in the tangent plane of n on the
+// Lagrangian (multiplier = o(n) by homogeneity; grad o = p_1 - p_2, the difference of the two witness points), with a step limit
+// and backtracking on o.  dist = -min o.
+CVX_FN Sym3 ell_matrix(const Geom &g) {
+  const M3 R = q2m(g.q);
+  const float a = g.s0 * g.s0, b = g.s1 * g.s1, c = g.s2 * g.s2;
+  return {a * R.m0 * R.m0 + b * R.m1 * R.m1 + c * R.m2 * R.m2, a * R.m3 * R.m3 + b * R.m4 * R.m4 + c * R.m5 * R.m5,
+          a * R.m6 * R.m6 + b * R.m7 * R.m7 + c * R.m8 * R.m8, a * R.m0 * R.m3 + b * R.m1 * R.m4 + c * R.m2 * R.m5,
+          a * R.m0 * R.m6 + b * R.m1 * R.m7 + c * R.m2 * R.m8, a * R.m3 * R.m6 + b * R.m4 * R.m7 + c * R.m5 * R.m8};
+}
+CVX_FN V3 sym_mv(const Sym3 &A, V3 v) { return {A.xx * v.x + A.xy * v.y + A.xz * v.z, A.xy * v.x + A.yy * v.y + A.yz * v.z, A.xz * v.x + A.yz * v.y + A.zz * v.z}; }
+template <int N_ITER>
+CVX_FN Result ell_ell(const Geom &a, const Geom &b, V3 n, bool have_n) {
+  const Sym3 A1 = ell_matrix(a), A2 = ell_matrix(b);
+  const V3 c = b.c - a.c;
+  if (!have_n) {
+    const float cl = fsqrt(dot(c, c));
+    n = cl > 1e-20f ? frcp(cl) * c : V3{1.f, 0.f, 0.f};
+  }
+  V3 u1 = sym_mv(A1, n), u2 = sym_mv(A2, n);
+  float h1 = fsqrt(dot(n, u1)), h2 = fsqrt(dot(n, u2)), o = h1 + h2 - dot(n, c);
+#pragma unroll 1
+  for (int it = 0; it < N_ITER; it++) {
+    const float i1 = frcp(h1), i2 = frcp(h2);
+    const V3 gr = i1 * u1 + i2 * u2 - c;
+    // Hessian of h_1 + h_2 minus o I, restricted to the tangent plane of n
+    const float k1 = i1 * i1 * i1, k2 = i2 * i2 * i2;
+    Sym3 Hs = add_s(add_s(scale_s(A1, i1), outer_s(u1, -k1)), add_s(scale_s(A2, i2), outer_s(u2, -k2)));
+    V3 t1 = fabsf(n.x) < 0.6f ? V3{0.f, -n.z, n.y} : V3{-n.z, 0.f, n.x};
+    t1 = frcp(fsqrt(dot(t1, t1))) * t1;
+    const V3 t2 = cross(n, t1);
+    const V3 Ht1 = sym_mv(Hs, t1), Ht2 = sym_mv(Hs, t2);
+    float m00 = dot(t1, Ht1) - o, m01 = dot(t1, Ht2), m11 = dot(t2, Ht2) - o;
+    const float r0 = -dot(t1, gr), r1 = -dot(t2, gr);
+    float det = m00 * m11 - m01 * m01;
+    if (!(m00 > 0.f && det > 1e-6f * m00 * m11)) {  // not positive definite (a deep overlap): fall back to the curvature part alone
+      m00 += fmaxf(o, 0.f) * 1.5f; m11 += fmaxf(o, 0.f) * 1.5f;
+      m00 = fmaxf(m00, 1e-12f); m11 = fmaxf(m11, 1e-12f);
+      det = fmaxf(m00 * m11 - m01 * m01, 1e-3f * m00 * m11);
+    }
+    const float idet = frcp(det);
+    float d0 = (m11 * r0 - m01 * r1) * idet, d1 = (m00 * r1 - m01 * r0) * idet;
+    const float dl2 = d0 * d0 + d1 * d1;
+    if (dl2 > 0.25f) { const float s = 0.5f * frcp(fsqrt(dl2)); d0 *= s; d1 *= s; }
+    bool moved = false;
+#pragma unroll 1
+    for (int bt = 0; bt < 4 && !moved; bt++) {
+      V3 nn = n + d0 * t1 + d1 * t2;
+      nn = frcp(fsqrt(dot(nn, nn))) * nn;
+      const V3 v1 = sym_mv(A1, nn), v2 = sym_mv(A2, nn);
+      const float g1 = fsqrt(dot(nn, v1)), g2 = fsqrt(dot(nn, v2)), on = g1 + g2 - dot(nn, c);
+      if (on <= o + 1e-7f * (h1 + h2)) { n = nn; u1 = v1; u2 = v2; h1 = g1; h2 = g2; o = on; moved = true; }
+      else { d0 *= 0.5f; d1 *= 0.5f; }
+    }
+    if (!moved) break;
+  }
+  Result r;
+  r.dist = -o;
+  r.n = n;
+  const V3 p1 = frcp(h1) * u1, p2 = c - frcp(h2) * u2;
+  r.pos = a.c + 0.5f * (p1 + p2);
+  return r;
+}
+
+
+// (3) An ellipsoid (geom1) against a cylinder (geom2), in the same dual form as (2).  The cylinder's support function
+// h_C(n) = R |n_perp| + H |n_z| (n_z = n . axis) has kinks on the great circle n_z = 0 (witness anywhere along a side-wall line) and at
+// the poles n = +-axis (witness anywhere on a cap), and those kinks are exactly where contacts with a side wall or a cap sit.  The
+// minimiser of o(n) = h_E(n) + h_C(n) + n . c (c = ellipsoid centre - cylinder centre, n from the ellipsoid to the cylinder) is
+// found by trying the three kinds of cylinder feature in turn, each with its exact optimality test:
+//   cap:  n = -+axis; optimal iff the ellipsoid's witness point lies over the cap disc;
+//   side: the minimiser on the circle n_z = 0 (one-dimensional Newton); optimal iff the ellipsoid's witness lies between the caps;
+//   rim:  else; o is smooth there: two-dimensional Newton as in (2), started towards the rim point nearest to the side solution.
+template <int N_ITER>
+CVX_FN Result ell_cyl(const Geom &e, const Geom &cy) {
+  const Sym3 A = ell_matrix(e);
+  const V3 c = e.c - cy.c, ax = zaxis(cy.q);
+  const float R = cy.s0, Hh = cy.s1;
+  Result r;
+  V3 n, u;
+  float h;
+  const float cz = dot(c, ax), sgn = cz >= 0.f ? 1.f : -1.f;
+  {  // cap
+    n = (-sgn) * ax;
+    u = sym_mv(A, n);
+    h = fsqrt(dot(n, u));
+    const V3 pe = c + frcp(h) * u, pr = pe - dot(pe, ax) * ax;
+    r.dist = -1e30f; r.n = n; r.pos = cy.c;
+    if (dot(pr, pr) <= R * R) {
+      r.dist = -(h + Hh + dot(n, c));
+      const V3 p2 = pr + (sgn * Hh) * ax;  // its projection on the cap
+      r.pos = cy.c + 0.5f * (pe + p2);
+      if (r.dist >= 0.f) return r;  // separated geoms have one stationary direction; overlapping ones may have one per feature: the
+    }                               // least overlap among them is kept (every direction's -o(n) is a lower bound of dist)
+  }
+  // side: n in the plane across the axis
+  {
+    V3 cp = c - cz * ax;
+    const float cl = fsqrt(dot(cp, cp));
+    if (cl > 1e-20f) n = (-frcp(cl)) * cp;
+    else { n = fabsf(ax.x) < 0.9f ? cross(ax, V3{1.f, 0.f, 0.f}) : cross(ax, V3{0.f, 1.f, 0.f}); n = frcp(fsqrt(dot(n, n))) * n; }
+  }
+  u = sym_mv(A, n);
+  h = fsqrt(dot(n, u));
+  float o = h + R + dot(n, c);
+#pragma unroll 1
+  for (int it = 0; it < N_ITER; it++) {
+    const float ih = frcp(h);
+    const V3 t = cross(ax, n), gr = ih * u + c;  // (the cylinder's own term R n adds nothing along t)
+    const V3 At = sym_mv(A, t);
+    const float ut = dot(u, t);
+    // along the circle: o' = gr . t, o'' = t' Hess(h_E) t - n . grad h_E = (t'At)/h - (u.t)^2/h^3 - h  ... minus the curvature term of the
+    // circle applied to the full gradient (n . gr), as in (2): o'' = t' Hs t - n . gr + R  (R: the cylinder's share of n . grad o)
+    const float d1 = dot(gr, t), d2 = dot(t, At) * ih - ut * ut * ih * ih * ih - dot(n, gr);
+    if (fabsf(d1) < 1e-9f) break;
+    float dth = d2 > 1e-9f ? -d1 * frcp(d2) : (d1 > 0.f ? -0.3f : 0.3f);
+    dth = fminf(fmaxf(dth, -0.5f), 0.5f);
+    bool moved = false;
+#pragma unroll 1
+    for (int bt = 0; bt < 4 && !moved; bt++) {
+      V3 nn = n + dth * t;
+      nn = frcp(fsqrt(dot(nn, nn))) * nn;
+      const V3 un = sym_mv(A, nn);
+      const float hn = fsqrt(dot(nn, un)), on = hn + R + dot(nn, c);
+      if (on <= o + 1e-7f * (h + R)) { n = nn; u = un; h = hn; o = on; moved = true; }
+      else dth *= 0.5f;
+    }
+    if (!moved) break;
+  }
+  {
+    const V3 pe = c + frcp(h) * u;
+    const float za = dot(pe, ax);
+    if (fabsf(za) <= Hh && -o > r.dist) {
+      r.dist = -o;
+      r.n = n;
+      const V3 p2 = za * ax - R * n;
+      r.pos = cy.c + 0.5f * (pe + p2);
+      if (r.dist >= 0.f) return r;
+    }
+    // rim: the cylinder's witness is a point z(psi) of the rim circle nearer to the ellipsoid's side witness; the contact is where
+    // the ellipsoid's signed distance along the circle is least (positive: gap, negative: depth along the ellipsoid's own normal) -
+    // one-dimensional Newton on psi with backtracking, started at the azimuth of the side witness
+    const float sr = za > 0.f ? 1.f : -1.f;
+    V3 pr = pe - za * ax;
+    const float pl = fsqrt(dot(pr, pr));
+    V3 e1 = pl > 1e-20f ? frcp(pl) * pr : V3{-n.x, -n.y, -n.z};
+    V3 e2 = cross(ax, e1);
+    Geom eg = e;
+    eg.c = c;  // (coordinates relative to the cylinder's centre)
+    const V3 zc = (sr * Hh) * ax;
+    V3 zr = R * e1, grad;
+    Sym3 Hq;
+    float f = sdf<true>(eg, zc + zr, grad, Hq);
+#pragma unroll 1
+    for (int it = 0; it < N_ITER; it++) {
+      // z = zc + zr, z' = R e2 (e2 = axis x e1), z'' = -zr
+      const V3 zp = R * e2;
+      const float d1 = dot(grad, zp), d2 = dot(zp, sym_mv(Hq, zp)) - dot(grad, zr);
+      if (fabsf(d1) < 1e-9f * R) break;
+      float dps = d2 > 1e-12f ? -d1 * frcp(d2) : (d1 > 0.f ? -0.3f : 0.3f);
+      dps = fminf(fmaxf(dps, -0.6f), 0.6f);
+      bool moved = false;
+#pragma unroll 1
+      for (int bt = 0; bt < 4 && !moved; bt++) {
+        V3 f1 = e1 + dps * e2;  // (a rotation to first order, renormalised: the step size itself needs no accuracy)
+        f1 = frcp(fsqrt(dot(f1, f1))) * f1;
+        V3 g2; Sym3 H2;
+        const float fn = sdf<true>(eg, zc + R * f1, g2, H2);
+        if (fn <= f + 1e-7f * (fabsf(f) + R)) { e1 = f1; e2 = cross(ax, e1); zr = R * e1; f = fn; grad = g2; Hq = H2; moved = true; }
+        else dps *= 0.5f;
+      }
+      if (!moved) break;
+    }
+    {
+      // the candidate's direction n = the ellipsoid's outward normal at its witness (from the ellipsoid to the cylinder); its rigorous
+      // value is the dual bound -o(n), which equals f when n lies in the rim's normal cone and falls far below it when it does not
+      const V3 un = sym_mv(A, grad);
+      const float nzr = dot(grad, ax);
+      const V3 mp = grad - nzr * ax;
+      const float orim = fsqrt(dot(grad, un)) + R * fsqrt(dot(mp, mp)) + Hh * fabsf(nzr) + dot(grad, c);
+      if (-orim > r.dist) {
+        r.dist = -orim;
+        r.n = grad;
+        r.pos = cy.c + zc + zr - (0.5f * f) * grad;
+      }
+    }
+    return r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// What the kernels call.  geom1 has the lower type code (mj_collision's order), so the normal points from geom1 to geom2.
+struct Contact { float dist; V3 n, pos; };
+
+// A rigorous lower bound of the pair's distance from one direction: u between the closest points of the two core segments
+// (-o(u) <= dist for every unit u).  The broad phase's second test: a pair whose bound exceeds its margin cannot touch.
+CVX_FN float separation_bound(const Geom &a, const Geom &b) {
+  V3 a1, a2;
+  float l1, l2, x1, x2;
+  core_segment(a, a1, l1); core_segment(b, a2, l2);
+  segment_closest(a.c, a1, l1, b.c, a2, l2, x1, x2);
+  V3 u = (b.c + x2 * a2) - (a.c + x1 * a1);
+  const float ul = fsqrt(dot(u, u));
+  if (!(ul > 1e-12f)) return -1e30f;  // the cores cross: no bound from this direction
+  u = frcp(ul) * u;
+  const V3 s1 = support(a, u), s2 = support(b, V3{-u.x, -u.y, -u.z});
+  return -dot(u, s1 - s2);
+}
+
+CVX_FN Contact collide(const Geom &g1, const Geom &g2) {
+  Contact out;
+  if (g1.type <= CAPSULE) {  // sphere / capsule against ellipsoid / cylinder
+    const PResult r = prim_convex<8>(g1, g2);
+    out.dist = r.dist; out.n = r.n; out.pos = r.pos;
+  } else if (g2.type == ELLIPSOID) {
+    const Result r = ell_ell<8>(g1, g2, V3{0.f, 0.f, 0.f}, false);
+    out.dist = r.dist; out.n = r.n; out.pos = r.pos;
+  } else if (g1.type == ELLIPSOID) {
+    const Result r = ell_cyl<12>(g1, g2);
+    out.dist = r.dist; out.n = r.n; out.pos = r.pos;
+  } else {  // cylinder - cylinder (the abdomen's segments among themselves; they never come near each other): the general iteration
+    const float sgap = 0.05f * fminf(g1.s0, g2.s0);
+    const Result r = distance<6, 4>(g1, g2, V3{0.f, 0.f, 0.f}, false, sgap, 1e30f);
+    out.dist = r.dist; out.n = r.n; out.pos = r.pos;
+  }
+  return out;
 }
 
 }  // namespace cvx

@@ -43,4 +43,44 @@ float cvxh_distance(const float *g1, const float *g2, const float *n0, int have_
   nrm[0] = r.n.x; nrm[1] = r.n.y; nrm[2] = r.n.z; pos[0] = r.pos.x; pos[1] = r.pos.y; pos[2] = r.pos.z;
   return r.dist;
 }
+// class-specialised routines: capsule / sphere against ellipsoid / cylinder, ellipsoid against ellipsoid
+float cvxh_prim_convex(const float *g1, const float *g2, int iters, float *nrm, float *pos, int *shallow) {
+  PResult r;
+  if (iters == 3) r = prim_convex<3>(mk(g1), mk(g2));
+  else if (iters == 4) r = prim_convex<4>(mk(g1), mk(g2));
+  else if (iters == 5) r = prim_convex<5>(mk(g1), mk(g2));
+  else if (iters == 6) r = prim_convex<6>(mk(g1), mk(g2));
+  else r = prim_convex<12>(mk(g1), mk(g2));
+  nrm[0] = r.n.x; nrm[1] = r.n.y; nrm[2] = r.n.z; pos[0] = r.pos.x; pos[1] = r.pos.y; pos[2] = r.pos.z;
+  *shallow = r.shallow ? 1 : 0;
+  return r.dist;
+}
+float cvxh_ell_ell(const float *g1, const float *g2, const float *n0, int have_n, int iters, float *nrm, float *pos) {
+  Result r;
+  const V3 n = {n0[0], n0[1], n0[2]};
+  if (iters == 3) r = ell_ell<3>(mk(g1), mk(g2), n, have_n != 0);
+  else if (iters == 4) r = ell_ell<4>(mk(g1), mk(g2), n, have_n != 0);
+  else if (iters == 6) r = ell_ell<6>(mk(g1), mk(g2), n, have_n != 0);
+  else if (iters == 8) r = ell_ell<8>(mk(g1), mk(g2), n, have_n != 0);
+  else r = ell_ell<16>(mk(g1), mk(g2), n, have_n != 0);
+  nrm[0] = r.n.x; nrm[1] = r.n.y; nrm[2] = r.n.z; pos[0] = r.pos.x; pos[1] = r.pos.y; pos[2] = r.pos.z;
+  return r.dist;
+}
+float cvxh_ell_cyl(const float *g1, const float *g2, int iters, float *nrm, float *pos) {
+  Result r;
+  if (iters == 3) r = ell_cyl<3>(mk(g1), mk(g2));
+  else if (iters == 4) r = ell_cyl<4>(mk(g1), mk(g2));
+  else if (iters == 6) r = ell_cyl<6>(mk(g1), mk(g2));
+  else if (iters == 8) r = ell_cyl<8>(mk(g1), mk(g2));
+  else r = ell_cyl<16>(mk(g1), mk(g2));
+  nrm[0] = r.n.x; nrm[1] = r.n.y; nrm[2] = r.n.z; pos[0] = r.pos.x; pos[1] = r.pos.y; pos[2] = r.pos.z;
+  return r.dist;
+}
+// the kernels' entry points: the pair dispatcher and the broad phase's separating-direction bound
+float cvxh_collide(const float *g1, const float *g2, float *nrm, float *pos) {
+  const Contact r = collide(mk(g1), mk(g2));
+  nrm[0] = r.n.x; nrm[1] = r.n.y; nrm[2] = r.n.z; pos[0] = r.pos.x; pos[1] = r.pos.y; pos[2] = r.pos.z;
+  return r.dist;
+}
+float cvxh_separation_bound(const float *g1, const float *g2) { return separation_bound(mk(g1), mk(g2)); }
 }
