@@ -17,7 +17,7 @@ PER_SOURCE_FLAGS = {
     "fly_env.hip": ["-mllvm", "-disable-machine-licm"],
     "ball_env.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
 }
-HEADERS = ["dev_model.hpp", "ball_model.hpp", "ball_env.hpp", "dev_math.hpp", "launch_order.hpp", os.path.join("..", "..", "include", "flybody_env.h")]
+HEADERS = ["dev_model.hpp", "ball_model.hpp", "ball_env.hpp", "dev_math.hpp", "convex.hpp", "launch_order.hpp", os.path.join("..", "..", "include", "flybody_env.h")]
 
 
 def needs_build() -> bool:

@@ -24,6 +24,7 @@
 #include "launch_order.hpp"
 #include "ball_model.hpp"
 #include "dev_math.hpp"
+#include "convex.hpp"
 
 namespace ffb {
 using namespace dm;
@@ -58,6 +59,12 @@ struct alignas(16) BState {
   float qacc_ws[NDP], wsc[NL][3];  // warm start of the constraint solver: last limit force per dof, last contact force per link
   int step_counter, needs_reset, overflow, iters, ncon, have_ws, nself, pad1;
   unsigned con_hist[2];  // active (inside includemargin) contacts of each of the control step's first 16 substeps, 4 bits each: parity tooling
+  unsigned det_hist[2];  // detected (inside margin) contacts of its first 12 substeps, 5 bits each
+  float sd_n[NSD][3];    // separating-direction cache of the convex pairs (convex_collide)
+  unsigned short sd_pid[NSD];
+  int sd_cnt, ws_n, pad2[2];
+  float ws_f[NC];        // forces of the fly-fly contacts of the last substep, by pair id (warm start)
+  unsigned short ws_pid[NC];
 };
 
 struct BTaskDev {
@@ -65,27 +72,38 @@ struct BTaskDev {
 };
 
 struct alignas(16) BTile {
+  // One scratch region, used by the phases of a substep in turn (7 488 B):
+  //   stage 1:    X4 / dadd / Mq (inertia, factorisation), F then lk (assembly, tree passes)
+  //   collision:  gc / gq / lp (geom frames, link poses) over the dead X4 .. Mq; primitive geom slots + the pair list in lk
+  //   stage 2:    Q, V / X4 (block solves) | G over the dead Mq and lk | Newton: S over everything (G is in registers by then)
   union {
     struct {
       union {
         struct { float Q[NDP], V[NDP]; };  // joint state staged for the actuators / contact rows (start of stage 2) and the observation
         float4 X4[NDP];                     // right-hand sides / solutions of the block solves
       };
-      float Mq[NMMAX], dadd[NDP];           // joint-space inertia and h * damping: only read by the stage-1 factorisation
+      float dadd[NDP];                      // h * damping: only read by the stage-1 factorisation
+      union {
+        struct {
+          float Mq[NMMAX];                  // joint-space inertia: only read by the stage-1 factorisation
+          union {
+            float F[NDP][6];                // crb * cdof during the inertia assembly
+            float lk[NL][12];               // link exchange of the tree passes: pose (7) | motion vector (6) | crb (10) | force (6)
+            struct { float pg[NPG * 9]; unsigned short cl1[CL1], cl2[64], tc_pid[NSD]; float tc_n[NSD][3]; };  // collision: primitive geom slots, pair lists, next cache
+          };
+        };
+        float G[RMAX * (RMAX + 1) / 2];     // stage 2: G = J M^-1 J' over the constraint rows, lower triangle packed by rows (lane r owns row r)
+      };
     };
-    float S[RMAX][RMAX + 1];                // Newton: I + L' G L and its Cholesky factor (no block solve is in flight then)
+    float S[RMAX * (RMAX + 1) / 2];         // Newton: the factor of I + L' G L, transposed through here (packed lower triangle)
+    struct { float4 gc[NG], gq[NG]; float lp[NL][8]; };  // collision: geom centre | bounding radius, geom quaternion; link pose
   };
   float Lm[NMMAX], Lh[NMMAX];               // factors of M and of M + h B (Euler), made together in stage 1
   float dinv_m[NDP], dinv_h[NDP];
   float C[NDP][6];
-  union {
-    float F[NDP][6];           // crb * cdof during the inertia assembly
-    float lk[NL][12];          // link exchange of the tree passes: pose (7) | motion vector (6) | crb (10) | force (6)
-    float G[RMAX * (RMAX + 1) / 2];  // stage 2: G = J M^-1 J' over the constraint rows, lower triangle packed by rows (lane r owns row r)
-  };
   float frc[64];
   int c_link[NC], c_blk[NC], c_excl[NC], c_nch[NC], c_adh[NC];
-  unsigned c_amask[NC], c_bmask[16];  // c_bmask[b]: contacts whose chain lies in block b
+  unsigned c_amask[NC], c_bmask[NBLK];  // c_bmask[b]: contacts whose chain lies in block b
   unsigned char c_chain[NC][16];
   float c_par[NC][5];  // K, B, invweight, friction, includemargin
   float c_pos[NC][3], c_frame[NC][9], c_dist[NC];
@@ -94,8 +112,16 @@ struct alignas(16) BTile {
   // constraint rows: 3 per contact (normal, two tangents), then the instantiated joint limits
   float r_y0[RMAX], r_lam[RMAX], r_f[RMAX];
   float r_sgn[RMAX], r_D[RMAX];
-  unsigned char r_blk[RMAX], r_col[RMAX], r_dof[RMAX], rowof[16][12];
+  unsigned char r_blk[RMAX], r_col[RMAX], r_dof[RMAX], rowof[NBLK][KCOL];
   float sens[24];  // running sums of the buffered sensors: force 18, touch 6
+  // separating directions of the convex pairs that reached the narrow phase, kept from substep to substep (convex_collide)
+  float sd_n[NSD][3];
+  unsigned short sd_pid[NSD];
+  int sd_cnt;
+  // fly-fly contacts: pair id of each slot, and the pairs' forces of the last substep (warm start of their rows)
+  unsigned short c_pid[NC], ws_pid[NC];
+  float ws_f[NC];
+  int ws_n;
 };
 
 // ------------------------------------------------------------------------------------------------ per-lane context
@@ -118,6 +144,7 @@ struct Ctx {
   V3 bw, btau;
   int nc, nact;           // ball contacts detected / of those, the ones inside includemargin (they get constraint rows)
   int nsc;                // fly-fly contacts of this substep: slots nc .. nc + nsc - 1 of the contact arrays (see self_collide)
+  int ndrop;              // detected fly-fly contacts without a slot (inactive, no adhesion actuator involved)
   float wsl[3], wsc[3];   // warm start of the constraint solver: last substep's limit force per slot, contact force of this link
   int have_ws, overflow;
 #ifdef FFB_STAMPS
@@ -392,7 +419,7 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
       if (dx * dx + dy * dy + dz * dz <= reach * reach) near |= 1u << (t - 1);
     }
   }
-  int nsc = 0, ovf = 0;
+  int nsc = 0, ovf = 0, ndrop = 0;
 #pragma unroll 1
   while (__ballot(near != 0u) != 0ull) {
     bool hit = false;
@@ -432,12 +459,19 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
       dist = cd - r1 - r2;
       cpos = q1 + (r1 + 0.5f * dist) * nrm;
     }
+    // A contact inside its margin but outside margin - gap exerts no force; it only matters as one of the contacts an adhesion
+    // actuator spreads its pull over (mjTRN_BODY).  Without such an actuator on either link it gets no slot (and no solver row);
+    // it is still counted (ndrop) so that the number of detected contacts stays MuJoCo's.
+    const bool dropped = hit && dist >= margin - (margin != 0.f ? M.sc_gap : 0.f) && M.l_adh[M.pgs_link[s1]] < 0 && M.l_adh[M.pgs_link[s2]] < 0;
+    hit = hit && !dropped;
+    ndrop += __popcll(__ballot(dropped));
     const unsigned long long bal = __ballot(hit);
     if (bal) {
       const int idx = nc + nsc + __popcll(bal & ((1ull << lane) - 1ull));
       if (hit && idx < NC) {
         const float incl = margin - (margin != 0.f ? M.sc_gap : 0.f);
         T.c_link[idx] = M.pgs_link[s1] | (M.pgs_link[s2] << 8);
+        T.c_pid[idx] = (unsigned short)(0x8000 | s1 | (s2 << 6));
         T.c_excl[idx] = dist >= incl ? 1 : 0;
         T.c_dist[idx] = dist;
         T.c_pos[idx][0] = cpos.x; T.c_pos[idx][1] = cpos.y; T.c_pos[idx][2] = cpos.z;
@@ -450,7 +484,205 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
       nsc = min(nsc + n, NC - nc);
     }
   }
-  return nsc | (ovf << 8);
+  return nsc | (ovf << 8) | (ndrop << 16);
+}
+
+// ------------------------------------------------------------------------------------------------ convex pairs
+// mj: mjc_Convex for the pairs with an ellipsoid or a cylinder on one side (thorax, head, rostrum, labrum, wings, coxae, abdomen
+// segments; fruitfly.xml:323-443), restated in csrc/convex.hpp.  The geoms' world frames are made once per substep from the link
+// poses the lanes publish (`T.lp`) into `T.gc` (centre | bounding radius) / `T.gq` (orientation).
+__device__ __forceinline__ cvx::Geom load_geom(const BTile &T, const BallModel FFE_GLOBAL &M, int g) {
+  const float4 cc = T.gc[g], qq = T.gq[g];
+  return cvx::Geom{V3{cc.x, cc.y, cc.z}, Q4{qq.x, qq.y, qq.z, qq.w}, M.cg_size[0][g], M.cg_size[1][g], M.cg_size[2][g], M.cg_type[g]};
+}
+
+// Ball (geom1, a sphere) against the ellipsoids / cylinders that can reach it (abdomen segments: mjc_SphereCylinder; labrum, wings:
+// the sphere's centre against the ellipsoid's signed distance): condim-3 ball contacts like the leg capsules', appended to the
+// `nc0` ball contacts stage 1 has just stored.  Also makes the geom frames for `convex_collide`.  Returns the number appended
+// | overflow << 8.
+__device__ __noinline__ int ball_convex(BTile *Tp, ModelPtr Mp, const int lane, const int nc0) {
+  BTile &T = *Tp;
+  const BallModel FFE_GLOBAL &M = *Mp;
+  const int ncg = M.ncg;
+  for (int g = lane; g < ncg; g += 64) {
+    const int l = M.cg_link[g];
+    V3 gp = {M.cg_pos[0][g], M.cg_pos[1][g], M.cg_pos[2][g]};
+    Q4 gq = {M.cg_quat[0][g], M.cg_quat[1][g], M.cg_quat[2][g], M.cg_quat[3][g]};
+    if (l >= 0) {
+      const float *lp = T.lp[l];
+      const Q4 xq = {lp[3], lp[4], lp[5], lp[6]};
+      gp = V3{lp[0], lp[1], lp[2]} + qrot(xq, gp);
+      gq = qnormalize(qmul(xq, gq));
+    }
+    T.gc[g] = make_float4(gp.x, gp.y, gp.z, M.cg_brad[g]);
+    T.gq[g] = make_float4(gq.w, gq.x, gq.y, gq.z);
+  }
+  DM_SYNC();
+  bool hit = false;
+  float dist = 0.f, incl = 0.f;
+  V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
+  const int nxb = M.nxb;
+  int g = 0;
+  if (lane < nxb) {
+    g = M.xb_geom[lane];
+    const cvx::Geom ball = {V3{M.b_center[0], M.b_center[1], M.b_center[2]}, Q4{1.f, 0.f, 0.f, 0.f}, M.b_radius, 0.f, 0.f, cvx::SPHERE};
+    const float4 cc = T.gc[g];
+    const float dx = cc.x - ball.c.x, dy = cc.y - ball.c.y, dz = cc.z - ball.c.z, reach = M.b_radius + cc.w + M.xb_margin[lane];
+    if (dx * dx + dy * dy + dz * dz <= reach * reach) {  // mj: the bounding-sphere test of mj_collision
+      const cvx::PResult r = cvx::prim_convex<1>(ball, load_geom(T, M, g));
+      dist = r.dist; nrm = r.n; cpos = r.pos;
+      hit = dist <= M.xb_margin[lane];
+      incl = M.xb_margin[lane] - M.xb_gap[lane];
+    }
+  }
+  const unsigned long long bal = __ballot(hit);
+  const int n = __popcll(bal), idx = nc0 + __popcll(bal & ((1ull << lane) - 1ull));
+  if (hit && idx < NC) {
+    const int link = M.cg_link[g], nch = M.l_nchain[link], last = M.l_chain[nch - 1][link];
+    T.c_link[idx] = link;
+    T.c_blk[idx] = M.d_blk[last]; T.c_amask[idx] = M.d_amask[last];
+    T.c_excl[idx] = dist >= incl ? 1 : 0;
+    T.c_dist[idx] = dist;
+    T.c_pos[idx][0] = cpos.x; T.c_pos[idx][1] = cpos.y; T.c_pos[idx][2] = cpos.z;
+    T.c_nch[idx] = nch;
+    for (int p = 0; p < NCH; p++) T.c_chain[idx][p] = (unsigned char)(p < nch ? M.l_chain[p][link] : 0);
+    T.c_par[idx][0] = M.xb_K[lane]; T.c_par[idx][1] = M.xb_B[lane]; T.c_par[idx][2] = M.xb_invw[lane]; T.c_par[idx][3] = M.xb_fric[lane];
+    T.c_par[idx][4] = incl;
+    T.c_adh[idx] = M.l_adh[link];
+    V3 t1 = (nrm.y < 0.5f && nrm.y > -0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};  // mj: mju_makeFrame
+    t1 = t1 - dot(nrm, t1) * nrm;
+    t1 = frcp(fsqrt(dot(t1, t1))) * t1;
+    const V3 t2 = cross(nrm, t1);
+    float *fr = T.c_frame[idx];
+    fr[0] = nrm.x; fr[1] = nrm.y; fr[2] = nrm.z; fr[3] = t1.x; fr[4] = t1.y; fr[5] = t1.z; fr[6] = t2.x; fr[7] = t2.y; fr[8] = t2.z;
+  }
+  DM_SYNC();
+  return min(n, NC - nc0) | ((nc0 + n > NC ? 1 : 0) << 8);
+}
+
+// The fly's own convex pairs.  Broad phase: MuJoCo's bounding-sphere test over the static candidate list (flybody_amd/model/reach.py),
+// then - on the survivors - a rigorous lower bound of the distance from one separating direction (cvx::separation_bound); a pair
+// whose bound exceeds its margin cannot touch.  Narrow phase: one lane per remaining pair (cvx::collide).  A contact (dist <= margin)
+// takes the next free slot after the `nprev` contacts already stored, in the same layout as self_collide's; a geom of the thorax
+// (fixed to the world) has no link: the moving geom's link is stored first and the normal turned, so that it still points from the
+// first link's geom to the second's.  Returns the number of contacts stored | overflow << 8.
+__device__ __noinline__ int convex_collide(BTile *Tp, ModelPtr Mp, const int lane, const int nprev) {
+  BTile &T = *Tp;
+  const BallModel FFE_GLOBAL &M = *Mp;
+  const unsigned long long mm0 = M.cg_mmask[0], mm1 = M.cg_mmask[1];
+  const float mclaw = M.sc_margin;
+  auto pair_margin = [&](int a, int b) {
+    const bool ma = a < 64 ? ((mm0 >> a) & 1ull) : ((mm1 >> (a - 64)) & 1ull), mb = b < 64 ? ((mm0 >> b) & 1ull) : ((mm1 >> (b - 64)) & 1ull);
+    return (ma || mb) ? mclaw : 0.f;
+  };
+  int n1 = 0, ovf = 0;
+#ifdef CVXDBG_NO_SPHERE
+  const int ncp = 0;
+#else
+  const int ncp = M.ncp;
+#endif
+#pragma unroll 2
+  for (int base = 0; base < ncp; base += 64) {
+    const unsigned w = M.cp_pair[base + lane];
+    bool pass = false;
+    if (w != 0xffffu) {
+      const int a = w & 255, b = w >> 8;
+      const float4 ca = T.gc[a], cb = T.gc[b];
+      const float dx = cb.x - ca.x, dy = cb.y - ca.y, dz = cb.z - ca.z, reach = ca.w + cb.w + pair_margin(a, b);
+      pass = dx * dx + dy * dy + dz * dz <= reach * reach;
+    }
+    const unsigned long long bal = __ballot(pass);
+    const int idx = n1 + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pass && idx < CL1) T.cl1[idx] = (unsigned short)w;
+    n1 += __popcll(bal);
+  }
+  if (n1 > CL1) { n1 = CL1; ovf = 1; }
+#ifdef CVXDBG_NO_BOUND
+  n1 = 0;
+#endif
+  DM_SYNC();
+  // Second test: a separating direction proves the pair apart.  Besides the two directions of cvx::separation_bound, the one the
+  // narrow phase found for this pair on the last substep it ran (`sd_*`): pairs that stay near each other without touching (a hind
+  // coxa beside the abdomen, stacked abdomen discs) then cost two support evaluations per substep instead of a narrow phase.
+  int n2 = 0, nk = 0;
+  const int ncache = T.sd_cnt;
+#pragma unroll 1
+  for (int base = 0; base < n1; base += 64) {
+    bool pass = false, keep = false;
+    unsigned w = 0u;
+    V3 kn = {0.f, 0.f, 0.f};
+    if (base + lane < n1) {
+      w = T.cl1[base + lane];
+      const int a = w & 255, b = w >> 8;
+      const cvx::Geom ga = load_geom(T, M, a), gb = load_geom(T, M, b);
+      const float margin = pair_margin(a, b);
+      pass = cvx::separation_bound(ga, gb) <= margin;
+      if (pass) {
+        for (int k = 0; k < ncache; k++) {
+          if (T.sd_pid[k] == w) {
+            kn = V3{T.sd_n[k][0], T.sd_n[k][1], T.sd_n[k][2]};
+            keep = -cvx::overlap(ga, gb, kn) > margin;
+          }
+        }
+        pass = !keep;
+      }
+    }
+    const unsigned long long bal = __ballot(pass), balk = __ballot(keep);
+    const int idx = n2 + __popcll(bal & ((1ull << lane) - 1ull)), idk = nk + __popcll(balk & ((1ull << lane) - 1ull));
+    if (pass && idx < 64) T.cl2[idx] = (unsigned short)w;
+    if (keep && idk < NSD) { T.tc_pid[idk] = (unsigned short)w; T.tc_n[idk][0] = kn.x; T.tc_n[idk][1] = kn.y; T.tc_n[idk][2] = kn.z; }
+    n2 += __popcll(bal);
+    nk = min(nk + __popcll(balk), NSD);
+  }
+  if (n2 > 64) { n2 = 64; ovf = 1; }
+#ifdef CVXDBG_NO_NARROW
+  n2 = 0;
+#endif
+  DM_SYNC();
+  bool hit = false, dropped = false;
+  float dist = 0.f, margin = 0.f;
+  V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
+  int a = 0, b = 0;
+  if (lane < n2) {
+    const unsigned w = T.cl2[lane];
+    a = w & 255; b = w >> 8;
+    margin = pair_margin(a, b);
+    const cvx::Contact ct = cvx::collide(load_geom(T, M, a), load_geom(T, M, b));
+    dist = ct.dist; nrm = ct.n; cpos = ct.pos;
+    hit = dist <= margin;
+    // (an inactive contact no adhesion actuator takes part in gets no slot: see self_collide)
+    if (hit && dist >= margin - (margin != 0.f ? M.sc_gap : 0.f)) {
+      const int la_ = M.cg_link[a], lb_ = M.cg_link[b];
+      dropped = (la_ < 0 || M.l_adh[la_] < 0) && (lb_ < 0 || M.l_adh[lb_] < 0);
+      hit = !dropped;
+    }
+    if (nk + lane < NSD) {  // its direction, for the next substep's second test
+      T.tc_pid[nk + lane] = (unsigned short)w; T.tc_n[nk + lane][0] = nrm.x; T.tc_n[nk + lane][1] = nrm.y; T.tc_n[nk + lane][2] = nrm.z;
+    }
+  }
+  nk = min(nk + n2, NSD);
+  DM_SYNC();
+  if (lane < nk) { T.sd_pid[lane] = T.tc_pid[lane]; T.sd_n[lane][0] = T.tc_n[lane][0]; T.sd_n[lane][1] = T.tc_n[lane][1]; T.sd_n[lane][2] = T.tc_n[lane][2]; }
+  if (lane == 0) T.sd_cnt = nk;
+  const unsigned long long bal = __ballot(hit);
+  const int n = __popcll(bal), idx = nprev + __popcll(bal & ((1ull << lane) - 1ull));
+  if (hit && idx < NC) {
+    int la = M.cg_link[a], lb = M.cg_link[b];
+    if (la < 0) { la = lb; lb = 255; nrm = V3{-nrm.x, -nrm.y, -nrm.z}; }
+    else if (lb < 0) lb = 255;
+    const float incl = margin - (margin != 0.f ? M.sc_gap : 0.f);
+    T.c_link[idx] = la | (lb << 8);
+    T.c_pid[idx] = (unsigned short)(a | (b << 8));
+    T.c_excl[idx] = dist >= incl ? 1 : 0;
+    T.c_dist[idx] = dist;
+    T.c_pos[idx][0] = cpos.x; T.c_pos[idx][1] = cpos.y; T.c_pos[idx][2] = cpos.z;
+    T.c_frame[idx][0] = nrm.x; T.c_frame[idx][1] = nrm.y; T.c_frame[idx][2] = nrm.z;
+    T.c_par[idx][0] = M.sc_K; T.c_par[idx][1] = M.sc_B; T.c_par[idx][2] = M.cg_invw[a] + M.cg_invw[b]; T.c_par[idx][3] = 0.f;
+    T.c_par[idx][4] = incl;
+  }
+  if (nprev + n > NC) ovf = 1;
+  DM_SYNC();
+  return min(n, NC - nprev) | (ovf << 8) | (__popcll(__ballot(dropped)) << 16);
 }
 
 // Fly-fly contact slots keep the dofs of geom2's chain (14 bytes), and the block-local solve column of that chain (byte 14),
@@ -470,7 +702,7 @@ __device__ __noinline__ void self_rows(BTile *Tp, ModelPtr Mp, const int lane, c
   for (int j = 0; j < nsc; j++) {
     const int k = nc + j, la = T.c_link[k] & 255, lb = T.c_link[k] >> 8;
     const int half = lane >> 4, p = lane & 15, link = half == 0 ? la : lb;
-    const int nch = half < 2 ? M.l_nchain[link] : 0;
+    const int nch = (half < 2 && link != 255) ? M.l_nchain[link] : 0;  // (link 255: a geom of the thorax, fixed to the world - no chain)
     float jv = 0.f, vv = 0.f;
     int f = 0;
     if (half < 2 && p < nch) {
@@ -487,11 +719,11 @@ __device__ __noinline__ void self_rows(BTile *Tp, ModelPtr Mp, const int lane, c
     }
     const float vel = wave_sum(jv * vv);
     if (lane == 0) {
-      const int na = M.l_nchain[la], nb = M.l_nchain[lb], fa = M.l_chain[na - 1][la], fb = M.l_chain[nb - 1][lb];
+      const int na = M.l_nchain[la], nb = lb != 255 ? M.l_nchain[lb] : 0, fa = M.l_chain[na - 1][la], fb = lb != 255 ? M.l_chain[nb - 1][lb] : fa;
       T.c_nch[k] = na | (nb << 8);
       T.c_blk[k] = (int)M.d_blk[fa] | ((int)M.d_blk[fb] << 8);
-      T.c_amask[k] = (unsigned)M.d_amask[fa] | ((unsigned)M.d_amask[fb] << 16);
-      T.c_adh[k] = (M.l_adh[la] & 255) | ((M.l_adh[lb] & 255) << 8);
+      T.c_amask[k] = (unsigned)M.d_amask[fa] | ((lb != 255 ? (unsigned)M.d_amask[fb] : 0u) << 16);
+      T.c_adh[k] = (M.l_adh[la] & 255) | (((lb != 255 ? M.l_adh[lb] : -1) & 255) << 8);
       const float K = T.c_par[k][0], B = T.c_par[k][1], invw = T.c_par[k][2], incl = T.c_par[k][4], dist = T.c_dist[k];
       float si_[5];
 #pragma unroll
@@ -566,7 +798,7 @@ __device__ __noinline__ void self_gacc(BTile *Tp, const int lane, const int nc, 
       const int gc = cb + q2;
       const float av = q2 == 0 ? acc.x : (q2 == 1 ? acc.y : (q2 == 2 ? acc.z : acc.w));
       if (gc == 0) T.r_y0[lane] += av;  // J a_s
-      else if (gc - 1 < 12) {
+      else if (gc - 1 < KCOL) {
         const int r2 = T.rowof[b][gc - 1];
         if (r2 <= lane) T.G[gtri + r2] += av;  // (255 = no such row)
       }
@@ -810,6 +1042,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     if (cd >= 1e-15f) nrm = frcp(cd) * dif;
     cpos = bc + (M.b_radius + 0.5f * dist) * nrm;
   }
+  BSTAMP(5);  // collision: the ball against the leg capsules
   unsigned long long bal = __ballot(hit);
   if (__popcll(bal) > NC) {
     // more contacts than the tile holds: the env is flagged and the NC DEEPEST are kept (dropping a deep one lets the leg sink in
@@ -849,7 +1082,19 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     fr[0] = nrm.x; fr[1] = nrm.y; fr[2] = nrm.z; fr[3] = t1.x; fr[4] = t1.y; fr[5] = t1.z; fr[6] = t2.x; fr[7] = t2.y; fr[8] = t2.z;
   }
   DM_SYNC();
-  if (lane < 16) {
+  // ---- the ball against the ellipsoids / cylinders that can reach it (more condim-3 ball contacts), and the geom frames of the
+  //      convex pairs below, from the link poses published here
+  if (!(c.flags & BF_NO_CONTACT)) {
+    float *o = T.lp[lane];
+    o[0] = c.xp.x; o[1] = c.xp.y; o[2] = c.xp.z; o[3] = c.xq.w; o[4] = c.xq.x; o[5] = c.xq.y; o[6] = c.xq.z;
+    DM_SYNC();
+    const int xb = __builtin_amdgcn_readfirstlane(ball_convex(c.T, (ModelPtr)c.M, lane, c.nc));
+    if (xb >> 8) c.overflow |= 1;
+    for (int k = c.nc; k < c.nc + (xb & 0xff); k++) c.nact += T.c_excl[k] ? 0 : 1;
+    c.nc += xb & 0xff;
+  }
+  BSTAMP(10);  // geom frames + the ball against its convex partners
+  if (lane < NBLK) {
     unsigned bm = 0u;
     for (int k = 0; k < c.nc; k++) if (T.c_blk[k] == lane) bm |= 1u << k;
     T.c_bmask[lane] = bm;
@@ -857,7 +1102,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
   // ---- mj: mj_collision over the fly's own sphere / capsule pairs (condim 1).  Every link publishes its primitive geoms
   //      (world centre, axis, half length, radius) into the link-exchange area, which is free between the factorisation and
   //      stage 2; the pair tests read them back from there.
-  c.nsc = 0;
+  c.nsc = 0; c.ndrop = 0;
   if (!(c.flags & BF_NO_CONTACT)) {
     if (lane == M.pg2_lane) {  // the rostrum's second capsule
       const V3 gc = c.xp + mv(xmat, V3{M.pg2_pos[0], M.pg2_pos[1], M.pg2_pos[2]});
@@ -874,11 +1119,18 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     const int sc = __builtin_amdgcn_readfirstlane(self_collide(c.T, (ModelPtr)c.M, lane, c.nc));  // wave-uniform by construction
 #endif
     c.nsc = sc & 0xff;
-    if (sc >> 8) c.overflow |= 1;
+    if ((sc >> 8) & 0xff) c.overflow |= 1;
+    c.ndrop = sc >> 16;
+    BSTAMP(11);  // sphere / capsule pairs
+    // ---- and over its pairs with an ellipsoid or cylinder on one side
+    const int cc = __builtin_amdgcn_readfirstlane(convex_collide(c.T, (ModelPtr)c.M, lane, c.nc + c.nsc));
+    c.nsc += cc & 0xff;
+    if ((cc >> 8) & 0xff) c.overflow |= 1;
+    c.ndrop += cc >> 16;
     for (int k = c.nc; k < c.nc + c.nsc; k++) c.nact += T.c_excl[k] ? 0 : 1;
   }
   DM_SYNC();
-  BSTAMP(5);  // collision
+  BSTAMP(12);  // convex pairs
 }
 
 // sum over the contacts whose chain contains fly dof (blk, li) of  sum_r J[c][r][p] * w[c][r]
@@ -1072,16 +1324,18 @@ __device__ __noinline__ int dense_newton(BTile *Tp, ModelPtr Mp, const int lane,
         if (k < R) w -= S_(k) * rl_f(w, k);
       w *= ipp;
       // transpose through LDS (this lane's column of Lt), then backward substitution Lt' u = D^-1 z
+      // (only the strict lower triangle is non-zero: packed by rows, row i at i (i - 1) / 2)
       if (lane < R) {
+        const int tri = lane * (lane - 1) / 2;
 #pragma unroll
-        for (int j = 0; j < RB; j++) if (j < R) T.S[lane][j] = S_(j);
+        for (int j = 0; j < RB; j++) if (j < lane) T.S[tri + j] = S_(j);
       }
       DM_SYNC();
 #pragma unroll
       for (int m = 0; m < RB / 2; m++) Sp[m] = f2{0.f, 0.f};
       if (lane < R) {
 #pragma unroll
-        for (int k = 0; k < RB; k++) if (k < R) setS(k, T.S[k][lane]);
+        for (int k = 0; k < RB; k++) if (k < R && k > lane) setS(k, T.S[k * (k - 1) / 2 + lane]);
       }
       DM_SYNC();
 #pragma unroll
@@ -1326,7 +1580,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       const int row = nrc + lane, k = nc + lane;
       T.r_sgn[row] = 0.f; T.r_D[row] = T.c_D[k]; T.r_dof[row] = (unsigned char)k; T.r_blk[row] = (unsigned char)(T.c_blk[k] & 0xff);
       T.r_y0[row] = -T.c_aref[k][0];
-      T.r_lam[row] = 0.f;
+      float l0 = 0.f;  // the same pair's force of the last substep
+      if (c.have_ws) { const int nw = T.ws_n; const unsigned pid = T.c_pid[k]; for (int j = 0; j < nw; j++) if (T.ws_pid[j] == pid) l0 = T.ws_f[j]; }
+      T.r_lam[row] = l0;
     }
     R += nsc;
   }
@@ -1353,7 +1609,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     T.r_blk[lane] = (unsigned char)T.c_blk[k];
     T.r_y0[lane] = T.c_Jb[k][r][0] * amb.x + T.c_Jb[k][r][1] * amb.y + T.c_Jb[k][r][2] * amb.z - T.c_aref[k][r];
   }
-  for (int k = lane; k < 16 * 12; k += 64) (&T.rowof[0][0])[k] = 255;
+  for (int k = lane; k < NBLK * KCOL; k += 64) (&T.rowof[0][0])[k] = 255;
   // warm start from the force this link's contact carried last substep
   if (c.have_ws) { for (int k = 0; k < nc; k++) if (T.c_link[k] == lane) { T.r_lam[3 * k] = c.wsc[0]; T.r_lam[3 * k + 1] = c.wsc[1]; T.r_lam[3 * k + 2] = c.wsc[2]; } }
   else if (lane < nrc) T.r_lam[lane] = 0.f;
@@ -1373,25 +1629,25 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     if (lane < R) {
       const int b = myb;
       T.r_col[lane] = (unsigned char)mycol;
-      if (mycol < 12) T.rowof[b][mycol] = (unsigned char)lane;
+      if (mycol < KCOL) T.rowof[b][mycol] = (unsigned char)lane;
       if (myb2 >= 0) {
         sc_chain_b(T, nc + lane - nrc)[14] = (unsigned char)mycol2;
-        if (mycol2 < 12) T.rowof[myb2][mycol2] = (unsigned char)lane;
+        if (mycol2 < KCOL) T.rowof[myb2][mycol2] = (unsigned char)lane;
         mycol = max(mycol, mycol2);
       } else if (nsc && lane >= nrc && lane < nrc + nsc) sc_chain_b(T, nc + lane - nrc)[14] = (unsigned char)mycol;
       mycol += 1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mycol = max(mycol, __shfl_xor(mycol, off));
-    if (mycol > 12) c.overflow |= 4;  // more than 12 rows in one block of M (e.g. five ball contacts on one leg): the env is flagged
+    if (mycol > KCOL) c.overflow |= 4;  // more than KCOL rows in one block of M: the env is flagged
                                      // (wave-uniform here: lane 0 reports it) and the rows without a column exert no force (below)
-    ncol = min(mycol, 12);
-    if (mycol > 12) {
+    ncol = min(mycol, KCOL);
+    if (mycol > KCOL) {
       // A row without a column would keep its force law but lose its own response (its row of G stays empty): an explicit spring
       // of stiffness D - the blow-ups tools/soak.py saw at saturated actions.  Such rows are switched off for this substep
       // instead: a contact as a whole (all three rows), a limit or fly-fly row through D = 0.
       DM_SYNC();
-      const bool nocol = lane < R && ((int)T.r_col[lane] >= 12 || (myb2 >= 0 && mycol2 >= 12));
+      const bool nocol = lane < R && ((int)T.r_col[lane] >= KCOL || (myb2 >= 0 && mycol2 >= KCOL));
       if (nocol) { if (lane < nrc) T.c_excl[lane / 3] = 1; else T.r_D[lane] = 0.f; }
     }
   }
@@ -1452,7 +1708,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         const int gc = cb + q2;
         const float av = q2 == 0 ? acc.x : (q2 == 1 ? acc.y : (q2 == 2 ? acc.z : acc.w));
         if (gc == 0) T.r_y0[lane] += av;  // J a_s
-        else if (gc - 1 < 12) {
+        else if (gc - 1 < KCOL) {
           const int r2 = T.rowof[b][gc - 1];
           if (r2 <= lane) T.G[gtri + r2] += av;  // (255 = no such row)
         }
@@ -1480,6 +1736,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     else if (R <= 22) iters = dense_newton<22>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
     else if (R <= 24) iters = dense_newton<24>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
     else if (R <= 28) iters = dense_newton<28>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    else if (R <= 32) iters = dense_newton<32>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
+    else if (R <= 40) iters = dense_newton<40>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
     else iters = dense_newton<RMAX>(c.T, mp_, lane, R, nrc, scale2, nslip, c.have_ws);
     BSTAMP(9);  // newton + noslip (dense, in registers)
   }
@@ -1487,7 +1745,11 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   BSTAMP(16);  // noslip
   // ---- constraint forces in joint space, final acceleration a = a_s + M^-1 J' f
   if (lane < nrc) T.c_f[lane / 3][lane % 3] = constrained ? T.r_f[lane] : 0.f;
-  if (nsc && lane < nsc) { T.c_f[nc + lane][0] = T.r_f[nrc + lane]; T.c_f[nc + lane][1] = 0.f; T.c_f[nc + lane][2] = 0.f; }
+  if (nsc && lane < nsc) {
+    T.c_f[nc + lane][0] = T.r_f[nrc + lane]; T.c_f[nc + lane][1] = 0.f; T.c_f[nc + lane][2] = 0.f;
+    T.ws_pid[lane] = T.c_pid[nc + lane]; T.ws_f[lane] = constrained ? T.r_f[nrc + lane] : 0.f;
+  }
+  if (lane == 0) T.ws_n = nsc;
   DM_SYNC();
   float qc[3], a[3];
 #pragma unroll
@@ -1683,18 +1945,22 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     if (!phys_only) step_counter++;
   }
   if (lane < 24) T.sens[lane] = 0.f;
+  if (lane < NSD) { T.sd_pid[lane] = S.sd_pid[lane]; T.sd_n[lane][0] = S.sd_n[lane][0]; T.sd_n[lane][1] = S.sd_n[lane][1]; T.sd_n[lane][2] = S.sd_n[lane][2]; }
+  if (lane == 0) { T.sd_cnt = do_reset ? 0 : S.sd_cnt; T.ws_n = do_reset ? 0 : S.ws_n; }
+  if (lane < NC) { T.ws_pid[lane] = S.ws_pid[lane]; T.ws_f[lane] = S.ws_f[lane]; }
   DM_SYNC();
   const int nsub = phys_only ? nphys : M.nsub;
   float qn2 = 0.f;
   // one copy of each stage: stage1 ; [stage2 ; stage1] x nsub.  A reset is stage1 ; stage2 without actuation and without
   // integrating (mj_forward, dm_control's after_reset); its sensors are the first sample of the buffers.
   if (do_reset) c.flags |= BF_NO_ACTUATION;
-  unsigned long long con_hist = 0ull;
+  unsigned long long con_hist = 0ull, det_hist = 0ull;
 #pragma unroll 1
   for (int s = 0;; s++) {
     stage1(c);
     if (!do_reset && s == nsub) break;
     if (s < 16) con_hist |= (unsigned long long)min(c.nact, 15) << (4 * s);
+    if (s < 12) det_hist |= (unsigned long long)min(c.nc + c.nsc + c.ndrop, 31) << (5 * s);
     float act_new;
     stage2(c, act_reg, ctrl_reg, act_new, !do_reset, iters, &qn2);
     if (do_reset) break;
@@ -1707,11 +1973,15 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
 #pragma unroll
   for (int s = 0; s < 3; s++) S.wsc[lane][s] = c.wsc[s];
   if (lane < NU) S.act[lane] = do_reset ? 0.f : act_reg;
+  if (lane < NSD) { S.sd_pid[lane] = T.sd_pid[lane]; S.sd_n[lane][0] = T.sd_n[lane][0]; S.sd_n[lane][1] = T.sd_n[lane][1]; S.sd_n[lane][2] = T.sd_n[lane][2]; }
+  if (lane == 0) { S.sd_cnt = T.sd_cnt; S.ws_n = T.ws_n; }
+  if (lane < NC) { S.ws_pid[lane] = T.ws_pid[lane]; S.ws_f[lane] = T.ws_f[lane]; }
   if (lane == 0) {
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
-    S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc + c.nsc; S.nself = c.nsc;
+    S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc + c.nsc + c.ndrop; S.nself = c.nsc + c.ndrop;
     S.con_hist[0] = (unsigned)con_hist; S.con_hist[1] = (unsigned)(con_hist >> 32);
+    S.det_hist[0] = (unsigned)det_hist; S.det_hist[1] = (unsigned)(det_hist >> 32);
     // key of the next launch's order: what a wave's lifetime varies with - Newton iterations over the step's substeps (4 us each)
     // and the number of contacts (40 us each; least-squares fit of the lifetimes in tools/wave_timeline.py's trace)
     cost[env] = min(255, iters + 10 * (c.nc + c.nsc));
@@ -1804,7 +2074,7 @@ __global__ void ball_set_state_kernel(BState *states, const double *qpos, const 
   BState &S = states[env];
   for (int k = t; k < 106; k += blockDim.x) { if (k < 4) S.ballq[k] = (float)qpos[(size_t)env * 106 + k]; else S.q[k - 4] = (float)qpos[(size_t)env * 106 + k]; }
   for (int k = t; k < 105; k += blockDim.x) { if (k < 3) S.ballw[k] = (float)qvel[(size_t)env * 105 + k]; else S.v[k - 3] = (float)qvel[(size_t)env * 105 + k]; }
-  if (t == 0) S.have_ws = 0;
+  if (t == 0) { S.have_ws = 0; S.sd_cnt = 0; S.ws_n = 0; }
 }
 __global__ void ball_act_kernel(BState *states, double *act, int batch, int set) {
   const int env = blockIdx.x, t = threadIdx.x;
@@ -1819,6 +2089,7 @@ __global__ void ball_task_state_kernel(const BState *states, int *ints, double *
   int *o = ints + (size_t)i * 8;
   o[0] = (int)S.con_hist[0]; o[1] = (int)S.con_hist[1]; o[2] = S.step_counter; o[3] = S.nself; o[4] = S.needs_reset; o[5] = S.ncon; o[6] = S.iters; o[7] = S.overflow;
   for (int k = 0; k < 8; k++) reals[(size_t)i * 8 + k] = 0.0;
+  reals[(size_t)i * 8] = (double)((unsigned long long)S.det_hist[0] | ((unsigned long long)S.det_hist[1] << 32));  // (60 bits used: exact up to 10 substeps)
 }
 
 // ================================================================================================ host side

@@ -583,19 +583,27 @@ CVX_FN Result ell_cyl(const Geom &e, const Geom &cy) {
 // What the kernels call.  geom1 has the lower type code (mj_collision's order), so the normal points from geom1 to geom2.
 struct Contact { float dist; V3 n, pos; };
 
-// A rigorous lower bound of the pair's distance from one direction: u between the closest points of the two core segments
-// (-o(u) <= dist for every unit u).  The broad phase's second test: a pair whose bound exceeds its margin cannot touch.
+// Overlap of the two geoms along the unit direction u (from geom1 to geom2): -o(u) is a rigorous lower bound of the pair's
+// distance for every u.
+CVX_FN float overlap(const Geom &a, const Geom &b, V3 u) {
+  const V3 s1 = support(a, u), s2 = support(b, V3{-u.x, -u.y, -u.z});
+  return dot(u, s1 - s2);
+}
+// The broad phase's second test: the better of two such bounds - u between the closest points of the two core segments (long
+// geoms side by side) and u between the two centres (flat geoms stacked on each other: the abdomen's discs).  A pair whose bound
+// exceeds its margin cannot touch.
 CVX_FN float separation_bound(const Geom &a, const Geom &b) {
   V3 a1, a2;
-  float l1, l2, x1, x2;
+  float l1, l2, x1, x2, best = -1e30f;
   core_segment(a, a1, l1); core_segment(b, a2, l2);
   segment_closest(a.c, a1, l1, b.c, a2, l2, x1, x2);
   V3 u = (b.c + x2 * a2) - (a.c + x1 * a1);
-  const float ul = fsqrt(dot(u, u));
-  if (!(ul > 1e-12f)) return -1e30f;  // the cores cross: no bound from this direction
-  u = frcp(ul) * u;
-  const V3 s1 = support(a, u), s2 = support(b, V3{-u.x, -u.y, -u.z});
-  return -dot(u, s1 - s2);
+  float ul = fsqrt(dot(u, u));
+  if (ul > 1e-12f) best = -overlap(a, b, frcp(ul) * u);  // (crossing cores: no bound from this direction)
+  u = b.c - a.c;
+  ul = fsqrt(dot(u, u));
+  if (ul > 1e-12f) best = fmaxf(best, -overlap(a, b, frcp(ul) * u));
+  return best;
 }
 
 CVX_FN Contact collide(const Geom &g1, const Geom &g2) {

@@ -109,6 +109,7 @@ def lib():
         L.fo_ball_obs_dim.argtypes = [vp]
         L.fo_ball_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_ball_env_hist.argtypes = [vp, ip, dp, C.c_int]
+        L.fo_ball_env_hist_detected.argtypes = [vp, ip, C.c_int]
         L.fo_set_measure_unsupported.argtypes = [vp, C.c_int]
         L.fo_unsupported_min_sep.restype = C.c_double
         L.fo_unsupported_min_sep.argtypes = [vp, vp, ip, ip]
@@ -421,6 +422,12 @@ class OracleBallEnv:
         counts, gaps = np.zeros(n, dtype=np.int32), np.zeros(n)
         self.L.fo_ball_env_hist(self.ptr, _ip(counts), _dp(gaps), n)
         return counts, gaps
+
+    def detected_history(self, n=10):
+        """Per substep of the last control step: contacts detected (inside their margin, active or not; adhesion acts on all of them)."""
+        counts = np.zeros(n, dtype=np.int32)
+        self.L.fo_ball_env_hist_detected(self.ptr, _ip(counts), n)
+        return counts
 
     def split(self, obs):
         out, o = {}, 0

@@ -83,4 +83,5 @@ float cvxh_collide(const float *g1, const float *g2, float *nrm, float *pos) {
   return r.dist;
 }
 float cvxh_separation_bound(const float *g1, const float *g2) { return separation_bound(mk(g1), mk(g2)); }
+float cvxh_overlap(const float *g1, const float *g2, const float *u) { return overlap(mk(g1), mk(g2), V3{u[0], u[1], u[2]}); }
 }

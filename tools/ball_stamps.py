@@ -11,9 +11,9 @@ import torch
 
 from flybody_amd import _capi, fly_envs
 
-NAMES = ["kinematics sweep", "velocity sweep", "body forces + subtree sweep", "joint forces + M assembly", "factor M and M + hB", "collision",
-         "actuation + contact rows", "smooth forces", "rows + G (block solves incl. a_s)", "newton + noslip (dense, registers)", "-", "-",
-         "-", "-", "-", "-", "-", "constraint forces + final/Euler solve", "sensors",
+NAMES = ["kinematics sweep", "velocity sweep", "body forces + subtree sweep", "joint forces + M assembly", "factor M and M + hB", "collision: ball vs leg capsules",
+         "actuation + contact rows", "smooth forces", "rows + G (block solves incl. a_s)", "newton + noslip (dense, registers)", "collision: geom frames + ball vs convex", "collision: sphere / capsule pairs",
+         "collision: convex pairs", "-", "-", "-", "-", "constraint forces + final/Euler solve", "sensors",
          "integration", "prologue + store"]
 B = 4096
 env = fly_envs.walk_on_ball(batch_size=B)
