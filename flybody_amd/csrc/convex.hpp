@@ -458,94 +458,74 @@ CVX_FN Result ell_ell(const Geom &a, const Geom &b, V3 n, bool have_n) {
 // h_C(n) = R |n_perp| + H |n_z| (n_z = n . axis) has kinks on the great circle n_z = 0 (witness anywhere along a side-wall line) and at
 // the poles n = +-axis (witness anywhere on a cap), and those kinks are exactly where contacts with a side wall or a cap sit.  The
 // minimiser of o(n) = h_E(n) + h_C(n) + n . c (c = ellipsoid centre - cylinder centre, n from the ellipsoid to the cylinder) is
-// found by trying the three kinds of cylinder feature in turn, each with its exact optimality test:
+// looked for on the three kinds of cylinder feature, each with its exact optimality test:
 //   cap:  n = -+axis; optimal iff the ellipsoid's witness point lies over the cap disc;
-//   side: the minimiser on the circle n_z = 0 (one-dimensional Newton); optimal iff the ellipsoid's witness lies between the caps;
-//   rim:  else; o is smooth there: two-dimensional Newton as in (2), started towards the rim point nearest to the side solution.
+//   side: the minimiser on the circle n_z = 0 (coarse scan of eight directions, then one-dimensional Newton); optimal iff the
+//         ellipsoid's witness lies between the caps;
+//   rim:  the cylinder's witness is a point z(psi) of a rim circle; the contact is where the ellipsoid's signed distance along the
+//         circle is least (positive: gap, negative: depth along the ellipsoid's own normal) - one-dimensional Newton on psi with
+//         backtracking from the best of a few starts (the azimuth of the side witness; the rim points deepest under either face of
+//         the ellipsoid's thinnest axis: a wing blade lying across the abdomen's edge); the candidate's value is its dual bound -o(n).
+// Separated geoms have one stationary direction; overlapping ones may have one per feature: the least overlap among them is kept
+// (every direction's -o(n) is a lower bound of dist).  With the pair's direction of the last substep (`have_n`) only the feature
+// that direction lies on is refined; the full search runs when that does not reproduce a valid contact near the old direction.
 template <int N_ITER>
-CVX_FN Result ell_cyl(const Geom &e, const Geom &cy) {
+CVX_FN Result ell_cyl(const Geom &e, const Geom &cy, V3 n0 = V3{0.f, 0.f, 0.f}, bool have_n = false) {
   const Sym3 A = ell_matrix(e);
   const V3 c = e.c - cy.c, ax = zaxis(cy.q);
   const float R = cy.s0, Hh = cy.s1;
   Result r;
-  V3 n, u;
-  float h;
-  const float cz = dot(c, ax), sgn = cz >= 0.f ? 1.f : -1.f;
-  {  // cap
-    n = (-sgn) * ax;
-    u = sym_mv(A, n);
-    h = fsqrt(dot(n, u));
+  r.dist = -1e30f; r.n = V3{1.f, 0.f, 0.f}; r.pos = cy.c;
+  Geom eg = e;
+  eg.c = c;  // (coordinates relative to the cylinder's centre)
+
+  auto cap = [&](float sgn) {
+    const V3 n = (-sgn) * ax, u = sym_mv(A, n);
+    const float h = fsqrt(dot(n, u));
     const V3 pe = c + frcp(h) * u, pr = pe - dot(pe, ax) * ax;
-    r.dist = -1e30f; r.n = n; r.pos = cy.c;
-    if (dot(pr, pr) <= R * R) {
-      r.dist = -(h + Hh + dot(n, c));
-      const V3 p2 = pr + (sgn * Hh) * ax;  // its projection on the cap
-      r.pos = cy.c + 0.5f * (pe + p2);
-      if (r.dist >= 0.f) return r;  // separated geoms have one stationary direction; overlapping ones may have one per feature: the
-    }                               // least overlap among them is kept (every direction's -o(n) is a lower bound of dist)
-  }
-  // side: n in the plane across the axis
-  {
-    V3 cp = c - cz * ax;
-    const float cl = fsqrt(dot(cp, cp));
-    if (cl > 1e-20f) n = (-frcp(cl)) * cp;
-    else { n = fabsf(ax.x) < 0.9f ? cross(ax, V3{1.f, 0.f, 0.f}) : cross(ax, V3{0.f, 1.f, 0.f}); n = frcp(fsqrt(dot(n, n))) * n; }
-  }
-  u = sym_mv(A, n);
-  h = fsqrt(dot(n, u));
-  float o = h + R + dot(n, c);
+    const float d = -(h + Hh + dot(n, c));
+    if (dot(pr, pr) <= R * R && d > r.dist) { r.dist = d; r.n = n; r.pos = cy.c + 0.5f * (pe + pr + (sgn * Hh) * ax); }
+  };
+  // side: Newton on the circle from `n` (unit, across the axis); returns the axial coordinate of the ellipsoid's witness
+  auto side = [&](V3 n, V3 &pe_out) -> float {
+    V3 u = sym_mv(A, n);
+    float h = fsqrt(dot(n, u)), o = h + R + dot(n, c);
 #pragma unroll 1
-  for (int it = 0; it < N_ITER; it++) {
-    const float ih = frcp(h);
-    const V3 t = cross(ax, n), gr = ih * u + c;  // (the cylinder's own term R n adds nothing along t)
-    const V3 At = sym_mv(A, t);
-    const float ut = dot(u, t);
-    // along the circle: o' = gr . t, o'' = t' Hess(h_E) t - n . grad h_E = (t'At)/h - (u.t)^2/h^3 - h  ... minus the curvature term of the
-    // circle applied to the full gradient (n . gr), as in (2): o'' = t' Hs t - n . gr + R  (R: the cylinder's share of n . grad o)
-    const float d1 = dot(gr, t), d2 = dot(t, At) * ih - ut * ut * ih * ih * ih - dot(n, gr);
-    if (fabsf(d1) < 1e-9f) break;
-    float dth = d2 > 1e-9f ? -d1 * frcp(d2) : (d1 > 0.f ? -0.3f : 0.3f);
-    dth = fminf(fmaxf(dth, -0.5f), 0.5f);
-    bool moved = false;
+    for (int it = 0; it < N_ITER; it++) {
+      const float ih = frcp(h);
+      const V3 t = cross(ax, n), gr = ih * u + c, At = sym_mv(A, t);
+      const float ut = dot(u, t), d1 = dot(gr, t), d2 = dot(t, At) * ih - ut * ut * ih * ih * ih - dot(n, gr);
+      if (fabsf(d1) < 1e-9f) break;
+      float dth = d2 > 1e-9f ? -d1 * frcp(d2) : (d1 > 0.f ? -0.3f : 0.3f);
+      dth = fminf(fmaxf(dth, -0.5f), 0.5f);
+      bool moved = false;
 #pragma unroll 1
-    for (int bt = 0; bt < 4 && !moved; bt++) {
-      V3 nn = n + dth * t;
-      nn = frcp(fsqrt(dot(nn, nn))) * nn;
-      const V3 un = sym_mv(A, nn);
-      const float hn = fsqrt(dot(nn, un)), on = hn + R + dot(nn, c);
-      if (on <= o + 1e-7f * (h + R)) { n = nn; u = un; h = hn; o = on; moved = true; }
-      else dth *= 0.5f;
+      for (int bt = 0; bt < 4 && !moved; bt++) {
+        V3 nn = n + dth * t;
+        nn = frcp(fsqrt(dot(nn, nn))) * nn;
+        const V3 un = sym_mv(A, nn);
+        const float hn = fsqrt(dot(nn, un)), on = hn + R + dot(nn, c);
+        if (on <= o + 1e-7f * (h + R)) { n = nn; u = un; h = hn; o = on; moved = true; }
+        else dth *= 0.5f;
+      }
+      if (!moved) break;
     }
-    if (!moved) break;
-  }
-  {
     const V3 pe = c + frcp(h) * u;
     const float za = dot(pe, ax);
-    if (fabsf(za) <= Hh && -o > r.dist) {
-      r.dist = -o;
-      r.n = n;
-      const V3 p2 = za * ax - R * n;
-      r.pos = cy.c + 0.5f * (pe + p2);
-      if (r.dist >= 0.f) return r;
-    }
-    // rim: the cylinder's witness is a point z(psi) of the rim circle nearer to the ellipsoid's side witness; the contact is where
-    // the ellipsoid's signed distance along the circle is least (positive: gap, negative: depth along the ellipsoid's own normal) -
-    // one-dimensional Newton on psi with backtracking, started at the azimuth of the side witness
-    const float sr = za > 0.f ? 1.f : -1.f;
-    V3 pr = pe - za * ax;
-    const float pl = fsqrt(dot(pr, pr));
-    V3 e1 = pl > 1e-20f ? frcp(pl) * pr : V3{-n.x, -n.y, -n.z};
-    V3 e2 = cross(ax, e1);
-    Geom eg = e;
-    eg.c = c;  // (coordinates relative to the cylinder's centre)
+    if (fabsf(za) <= Hh && -o > r.dist) { r.dist = -o; r.n = n; r.pos = cy.c + 0.5f * (pe + za * ax - R * n); }
+    pe_out = pe;
+    return za;
+  };
+  auto rim_f = [&](float sr, V3 e1) { V3 g; Sym3 Hq; return sdf<false>(eg, (sr * Hh) * ax + R * e1, g, Hq); };
+  auto rim = [&](float sr, V3 e1) {
+    V3 e2 = cross(ax, e1), grad;
     const V3 zc = (sr * Hh) * ax;
-    V3 zr = R * e1, grad;
+    V3 zr = R * e1;
     Sym3 Hq;
     float f = sdf<true>(eg, zc + zr, grad, Hq);
 #pragma unroll 1
     for (int it = 0; it < N_ITER; it++) {
-      // z = zc + zr, z' = R e2 (e2 = axis x e1), z'' = -zr
-      const V3 zp = R * e2;
+      const V3 zp = R * e2;  // z = zc + zr, z' = R e2 (e2 = axis x e1), z'' = -zr
       const float d1 = dot(grad, zp), d2 = dot(zp, sym_mv(Hq, zp)) - dot(grad, zr);
       if (fabsf(d1) < 1e-9f * R) break;
       float dps = d2 > 1e-12f ? -d1 * frcp(d2) : (d1 > 0.f ? -0.3f : 0.3f);
@@ -562,21 +542,144 @@ CVX_FN Result ell_cyl(const Geom &e, const Geom &cy) {
       }
       if (!moved) break;
     }
+    // the candidate's direction n = the ellipsoid's outward normal at its witness (from the ellipsoid to the cylinder); its rigorous
+    // value is the dual bound -o(n), which equals f when n lies in the rim's normal cone and falls far below it when it does not
+    const V3 un = sym_mv(A, grad);
+    const float nzr = dot(grad, ax);
+    const V3 mp = grad - nzr * ax;
+    const float orim = fsqrt(dot(grad, un)) + R * fsqrt(dot(mp, mp)) + Hh * fabsf(nzr) + dot(grad, c);
+    if (-orim > r.dist) { r.dist = -orim; r.n = grad; r.pos = cy.c + zc + zr - (0.5f * f) * grad; }
+  };
+  // rim, dual form: o is smooth where n_z and n_perp both differ from zero - two-dimensional Newton as in (2), kept on the side
+  // sz of the kink n_z = 0.  Needed where the ellipsoid's own edge is the contact (a wing blade's edge on the abdomen's rim: the
+  // overlap then exceeds the blade edge's radius of curvature and the deepest rim point is no longer the witness).
+  auto rim_dual = [&](V3 n, float sz) {
     {
-      // the candidate's direction n = the ellipsoid's outward normal at its witness (from the ellipsoid to the cylinder); its rigorous
-      // value is the dual bound -o(n), which equals f when n lies in the rim's normal cone and falls far below it when it does not
-      const V3 un = sym_mv(A, grad);
-      const float nzr = dot(grad, ax);
-      const V3 mp = grad - nzr * ax;
-      const float orim = fsqrt(dot(grad, un)) + R * fsqrt(dot(mp, mp)) + Hh * fabsf(nzr) + dot(grad, c);
-      if (-orim > r.dist) {
-        r.dist = -orim;
-        r.n = grad;
-        r.pos = cy.c + zc + zr - (0.5f * f) * grad;
-      }
+      const float nz = dot(n, ax);
+      if (nz * sz < 0.1f) { n = n + (0.1f * sz - nz) * ax; n = frcp(fsqrt(dot(n, n))) * n; }
     }
-    return r;
+    auto hc = [&](V3 m, V3 &gc) {  // h_C and its gradient (the cylinder's support point relative to its centre)
+      const float mz = dot(m, ax);
+      const V3 mp = m - mz * ax;
+      const float ml = fsqrt(dot(mp, mp));
+      gc = (ml > 1e-20f ? R * frcp(ml) : 0.f) * mp + (sz * Hh) * ax;
+      return R * ml + Hh * fabsf(mz);
+    };
+    V3 gc, u = sym_mv(A, n);
+    float h = fsqrt(dot(n, u)), h2 = hc(n, gc), o = h + h2 + dot(n, c);
+#pragma unroll 1
+    for (int it = 0; it < N_ITER; it++) {
+      const float ih = frcp(h);
+      const V3 gr = ih * u + gc + c;
+      Sym3 Hs = add_s(scale_s(A, ih), outer_s(u, -ih * ih * ih));
+      {  // cylinder: R (I - ax ax' - e e') / |n_perp|
+        const float mz = dot(n, ax);
+        const V3 mp = n - mz * ax;
+        const float ml = fsqrt(dot(mp, mp)), k = ml > 1e-6f ? R * frcp(ml) : 0.f;
+        const V3 ee = ml > 1e-6f ? frcp(ml) * mp : V3{0.f, 0.f, 0.f};
+        Hs.xx += k; Hs.yy += k; Hs.zz += k;
+        Hs = add_s(Hs, add_s(outer_s(ax, -k), outer_s(ee, -k)));
+      }
+      V3 t1 = fabsf(n.x) < 0.6f ? V3{0.f, -n.z, n.y} : V3{-n.z, 0.f, n.x};
+      t1 = frcp(fsqrt(dot(t1, t1))) * t1;
+      const V3 t2 = cross(n, t1), Ht1 = sym_mv(Hs, t1), Ht2 = sym_mv(Hs, t2);
+      float m00 = dot(t1, Ht1) - o, m01 = dot(t1, Ht2), m11 = dot(t2, Ht2) - o;
+      const float r0 = -dot(t1, gr), r1 = -dot(t2, gr);
+      if (r0 * r0 + r1 * r1 < 1e-17f) break;
+      float det = m00 * m11 - m01 * m01;
+      if (!(m00 > 0.f && det > 1e-6f * m00 * m11)) {
+        m00 += fmaxf(o, 0.f) * 1.5f; m11 += fmaxf(o, 0.f) * 1.5f;
+        m00 = fmaxf(m00, 1e-12f); m11 = fmaxf(m11, 1e-12f);
+        det = fmaxf(m00 * m11 - m01 * m01, 1e-3f * m00 * m11);
+      }
+      const float idet = frcp(det);
+      float d0 = (m11 * r0 - m01 * r1) * idet, d1 = (m00 * r1 - m01 * r0) * idet;
+      const float dl2 = d0 * d0 + d1 * d1;
+      if (dl2 > 0.09f) { const float sc = 0.3f * frcp(fsqrt(dl2)); d0 *= sc; d1 *= sc; }
+      bool moved = false;
+#pragma unroll 1
+      for (int bt = 0; bt < 5 && !moved; bt++) {
+        V3 nn = n + d0 * t1 + d1 * t2;
+        nn = frcp(fsqrt(dot(nn, nn))) * nn;
+        V3 gcn;
+        const V3 un = sym_mv(A, nn);
+        const float hn = fsqrt(dot(nn, un)), h2n = hc(nn, gcn), on = hn + h2n + dot(nn, c);
+        if (dot(nn, ax) * sz > 1e-4f && on <= o + 1e-7f * (h + h2)) { n = nn; u = un; h = hn; h2 = h2n; gc = gcn; o = on; moved = true; }
+        else { d0 *= 0.5f; d1 *= 0.5f; }
+      }
+      if (!moved) break;
+    }
+    if (-o > r.dist + 2e-7f * R) {  // (a candidate equal to the one already held to rounding does not replace it)
+      r.dist = -o; r.n = n;
+      const V3 p1 = c + frcp(h) * u, p2 = V3{-gc.x, -gc.y, -gc.z};
+      r.pos = cy.c + 0.5f * (p1 + p2);
+    }
+  };
+  auto across = [&](V3 v, V3 fallback) {  // unit vector of v's part across the axis
+    const V3 w = v - dot(v, ax) * ax;
+    const float wl = fsqrt(dot(w, w));
+    return wl > 1e-12f ? frcp(wl) * w : fallback;
+  };
+  V3 b1 = fabsf(ax.x) < 0.9f ? cross(ax, V3{1.f, 0.f, 0.f}) : cross(ax, V3{0.f, 1.f, 0.f});
+  b1 = frcp(fsqrt(dot(b1, b1))) * b1;
+
+  if (have_n) {  // refine the feature the pair's last direction lies on
+    const float nz = dot(n0, ax);
+    V3 pe;
+    if (fabsf(nz) > 0.99995f) cap(nz > 0.f ? -1.f : 1.f);
+    else if (fabsf(nz) < 2e-3f) side(across(n0, b1), pe);
+    else rim_dual(n0, nz > 0.f ? 1.f : -1.f);
+    if (r.dist > -1e29f && dot(r.n, n0) > 0.95f) return r;
+    r.dist = -1e30f;
   }
+  const float cz = dot(c, ax);
+  cap(cz >= 0.f ? 1.f : -1.f);
+  if (r.dist >= 0.f) return r;
+  // side: best of eight directions around the axis as the start
+  V3 pe;
+  float za;
+  {
+    const V3 b2 = cross(ax, b1);
+    V3 nbest = b1;
+    float obest = 1e30f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float cs = k == 0 ? 1.f : k == 1 ? 0.70710678f : k == 2 ? 0.f : k == 3 ? -0.70710678f : k == 4 ? -1.f : k == 5 ? -0.70710678f : k == 6 ? 0.f : 0.70710678f;
+      const float sn = k == 0 ? 0.f : k == 1 ? 0.70710678f : k == 2 ? 1.f : k == 3 ? 0.70710678f : k == 4 ? 0.f : k == 5 ? -0.70710678f : k == 6 ? -1.f : -0.70710678f;
+      const V3 n = cs * b1 + sn * b2;
+      const float o = fsqrt(dot(n, sym_mv(A, n))) + dot(n, c);
+      if (o < obest) { obest = o; nbest = n; }
+    }
+    const float dprev = r.dist;
+    za = side(nbest, pe);
+    if (r.dist >= 0.f && r.dist > dprev) return r;
+  }
+  // rim: the best of a few starts
+  {
+    const M3 Re = q2m(e.q);
+    const V3 m = e.s0 <= e.s1 && e.s0 <= e.s2 ? V3{Re.m0, Re.m3, Re.m6} : (e.s1 <= e.s2 ? V3{Re.m1, Re.m4, Re.m7} : V3{Re.m2, Re.m5, Re.m8});  // thinnest axis
+    const V3 em = across(m, b1), es = across(pe, V3{-b1.x, -b1.y, -b1.z});
+    const float s0 = za > 0.f ? 1.f : -1.f;
+    float sr = s0, fb = rim_f(s0, es);
+    V3 eb = es;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float s = k < 2 ? 1.f : -1.f;
+      const V3 e1 = (k & 1) ? em : V3{-em.x, -em.y, -em.z};
+      const float f = rim_f(s, e1);
+      if (f < fb) { fb = f; sr = s; eb = e1; }
+    }
+    rim(sr, eb);
+    const V3 nb = r.dist > -1e29f ? r.n : V3{-es.x, -es.y, -es.z};
+    rim_dual(nb, 1.f);
+    rim_dual(nb, -1.f);
+    // and from the ellipsoid's thinnest axis (a blade pressed flat over the rim: the direction of least overlap is close to the
+    // blade's normal), towards the cylinder
+    const V3 mt = dot(m, c) > 0.f ? V3{-m.x, -m.y, -m.z} : m;
+    rim_dual(mt, 1.f);
+    rim_dual(mt, -1.f);
+  }
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -606,16 +709,48 @@ CVX_FN float separation_bound(const Geom &a, const Geom &b) {
   return best;
 }
 
-CVX_FN Contact collide(const Geom &g1, const Geom &g2) {
+// mj: mjc_CapsuleCapsule (closest points of the two axis segments, one contact); a sphere is a capsule of zero length, for which
+// the same formulas are mjc_SphereCapsule / mjraw_SphereSphere
+CVX_FN Contact capsule_capsule(const Geom &a, const Geom &b) {
+  const V3 a1 = zaxis(a.q), a2 = zaxis(b.q);
+  const float l1 = a.type == CAPSULE ? a.s1 : 0.f, l2 = b.type == CAPSULE ? b.s1 : 0.f;
+  float x1, x2;
+  {  // (mjc_CapsuleCapsule's own case split: kept apart from segment_closest, whose clamping order differs in the last digit)
+    const V3 dif = a.c - b.c;
+    const float mb = -dot(a1, a2), u = -dot(a1, dif), v = dot(a2, dif), det = 1.f - mb * mb;
+    if (fabsf(det) >= 1e-6f) {
+      const float idet = 1.f / det;
+      x1 = (u - mb * v) * idet; x2 = (v - mb * u) * idet;
+      if (x1 > l1) { x1 = l1; x2 = v - mb * l1; } else if (x1 < -l1) { x1 = -l1; x2 = v + mb * l1; }
+      if (x2 > l2) { x2 = l2; x1 = fminf(fmaxf(u - mb * l2, -l1), l1); }
+      else if (x2 < -l2) { x2 = -l2; x1 = fminf(fmaxf(u + mb * l2, -l1), l1); }
+    } else {  // parallel axes: centre of the overlapping stretch
+      const float c2 = u, lo = fmaxf(-l1, c2 - l2), hi = fminf(l1, c2 + l2);
+      x1 = lo <= hi ? 0.5f * (lo + hi) : (c2 > 0.f ? l1 : -l1);
+      x2 = fminf(fmaxf((x1 - c2) * (mb < 0.f ? 1.f : -1.f), -l2), l2);
+    }
+  }
+  const V3 q1 = a.c + x1 * a1, q2 = b.c + x2 * a2, d12 = q2 - q1;
+  const float cd = fsqrt(dot(d12, d12));
   Contact out;
+  out.n = cd >= 1e-15f ? frcp(cd) * d12 : V3{1.f, 0.f, 0.f};
+  out.dist = cd - a.s0 - b.s0;
+  out.pos = q1 + (a.s0 + 0.5f * out.dist) * out.n;
+  return out;
+}
+
+// (`n0`: the pair's direction of the last substep, when `have_n`: the ellipsoid classes then refine it instead of searching)
+CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}, bool have_n = false) {
+  Contact out;
+  if (g2.type <= CAPSULE) return capsule_capsule(g1, g2);
   if (g1.type <= CAPSULE) {  // sphere / capsule against ellipsoid / cylinder
     const PResult r = prim_convex<8>(g1, g2);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
   } else if (g2.type == ELLIPSOID) {
-    const Result r = ell_ell<8>(g1, g2, V3{0.f, 0.f, 0.f}, false);
+    const Result r = ell_ell<8>(g1, g2, n0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
   } else if (g1.type == ELLIPSOID) {
-    const Result r = ell_cyl<12>(g1, g2);
+    const Result r = ell_cyl<12>(g1, g2, n0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
   } else {  // cylinder - cylinder (the abdomen's segments among themselves; they never come near each other): the general iteration
     const float sgap = 0.05f * fminf(g1.s0, g2.s0);

@@ -35,6 +35,8 @@ constexpr int kMaxWrap = 8;   // transmission terms per actuator (joint: 1, fixe
 constexpr int kMaxObsJ = 32;
 constexpr int kMaxFuture = 8;
 constexpr int kLanePad = 64;  // every lane-major table is padded to a full wave
+constexpr int kMaxGeom = 72;   // collision geoms (70), padded
+constexpr int kMaxPair = 384;  // candidate collision pairs (362), padded to whole waves
 
 // ------------------------------------------------------------------------------------------------ blob
 struct Tensor {
@@ -72,6 +74,7 @@ class Blob {
       tensors_[name] = t;
     }
   }
+  bool has(const std::string &name) const { return tensors_.count(name) != 0; }
   const Tensor &get(const std::string &name) const {
     auto it = tensors_.find(name);
     if (it == tensors_.end()) throw std::runtime_error("model blob: missing tensor " + name);
@@ -124,6 +127,17 @@ struct DevModel {
   const int FFE_GLOBAL *wing_dof, *wing_qadr, *wing_action, *wing_ctrl, *obsj_qadr, *obsj_dof;  // wing_ctrl: ctrl slot fed by the wing's action entry
   int user_action;
   const float FFE_GLOBAL *qpos0;  // [nq]
+  // ---- collision geoms (ref: tasks/base.py:299-302 disables the floor only: the fly's own geoms still collide in flight).  All
+  //      70 geoms in model order, frames in their link (cg_pos [3][kMaxGeom], cg_quat [4][.], cg_size [3][.]); cp_pair = the static
+  //      candidate list (flybody_amd/model/reach.py), g1 | g2 << 8 with g1 the lower type code (mj_collision's order), 0xffff padding;
+  //      l_dofmask[l] = dofs that move link l.  ncg == 0: a model blob without geoms (contact-free configurations).
+  int ncg, ncp;
+  float c_margin, c_gap, c_K, c_B, c_solimp[5];
+  unsigned long long cg_mmask[2];  // geoms that carry the margin / gap (labrum, claws)
+  const int FFE_GLOBAL *cg_link, *cg_type;
+  const float FFE_GLOBAL *cg_pos, *cg_quat, *cg_size, *cg_brad, *cg_invw;
+  const unsigned short FFE_GLOBAL *cp_pair;
+  const unsigned long long FFE_GLOBAL *l_dofmask;
 };
 
 struct BoxCoef { float c[8]; };  // visc_ang, visc_lin, quad_lin[3], quad_ang[3]
@@ -193,6 +207,8 @@ struct HostModel {
     fix(dst.a_fhi);
     fix(dst.wing_dof); fix(dst.wing_qadr); fix(dst.wing_action); fix(dst.wing_ctrl); fix(dst.obsj_qadr); fix(dst.obsj_dof);
     fix(dst.qpos0);
+    fix(dst.cg_link); fix(dst.cg_type); fix(dst.cg_pos); fix(dst.cg_quat); fix(dst.cg_size); fix(dst.cg_brad); fix(dst.cg_invw);
+    fix(dst.cp_pair); fix(dst.l_dofmask);
   }
 };
 
@@ -533,6 +549,58 @@ inline HostModel build_host_model(const Blob &b) {
   for (int c = 1; c <= 3; c++) if (site.f(c) != 0.0) throw std::runtime_error("sensor site must sit at the root body origin");
   if (site.f(4) != 1.0) throw std::runtime_error("sensor site must share the root body orientation");
 
+  // ---- collision ------------------------------------------------------------------------------------
+  std::vector<int> cg_link(kMaxGeom, 0), cg_type(kMaxGeom, 0);
+  std::vector<float> cg_pos(3 * kMaxGeom, 0.f), cg_quat(4 * kMaxGeom, 0.f), cg_size(3 * kMaxGeom, 0.f), cg_brad(kMaxGeom, 0.f), cg_invw(kMaxGeom, 0.f);
+  std::vector<unsigned short> cp_pair(kMaxPair, 0xffffu);
+  std::vector<unsigned long long> l_dofmask(kMaxLink + 1, 0ull);
+  V.ncg = V.ncp = 0; V.cg_mmask[0] = V.cg_mmask[1] = 0ull;
+  V.c_margin = V.c_gap = V.c_K = V.c_B = 0.f;
+  for (int d = 0; d < nv; d++) {  // a dof moves its own link and every link below it
+    const int lk = d_link[d];
+    for (int k = 0; k < nl; k++) {
+      bool below = false;
+      for (int a = k; a >= 0; a = lparent.i(a)) below |= (a == lk);
+      if (below) l_dofmask[k] |= 1ull << d;
+    }
+  }
+  if (b.has("cgeom_link")) {
+    const Tensor &gl = b.get("cgeom_link"), &gp = b.get("cgeom_pos"), &gq = b.get("cgeom_quat"), &gt = b.get("geom_type"), &gs = b.get("geom_size"),
+                 &gm = b.get("geom_margin"), &gg = b.get("geom_gap"), &gsr = b.get("geom_solref"), &gsi = b.get("geom_solimp"), &gcd = b.get("geom_condim"),
+                 &gb = b.get("geom_bodyid"), &biw = b.get("body_invweight0"), &c1 = b.get("cand_g1"), &c2 = b.get("cand_g2");
+    const int ng = static_cast<int>(gl.count);
+    if (ng > kMaxGeom || static_cast<int>(c1.count) > kMaxPair) throw std::runtime_error("collision tables exceed kernel capacities");
+    V.ncg = ng;
+    for (int g = 0; g < ng; g++) {
+      const int ty = gt.i(g);
+      if (ty < 2 || ty > 5) throw std::runtime_error("flight model: unexpected geom type");
+      if (gcd.i(g) != 1) throw std::runtime_error("flight model: fly geoms are expected to be condim 1");
+      cg_link[g] = gl.i(g); cg_type[g] = ty;
+      for (int c = 0; c < 3; c++) { cg_pos[c * kMaxGeom + g] = static_cast<float>(gp.f(3 * g + c)); cg_size[c * kMaxGeom + g] = static_cast<float>(gs.f(3 * g + c)); }
+      for (int c = 0; c < 4; c++) cg_quat[c * kMaxGeom + g] = static_cast<float>(gq.f(4 * g + c));
+      const double s0 = gs.f(3 * g), s1 = gs.f(3 * g + 1), s2 = gs.f(3 * g + 2);
+      cg_brad[g] = static_cast<float>(ty == 2 ? s0 : ty == 3 ? s0 + s1 : ty == 5 ? std::sqrt(s0 * s0 + s1 * s1) : std::fmax(s0, std::fmax(s1, s2)));
+      cg_invw[g] = static_cast<float>(biw.f(2 * gb.i(g)));
+      // mj_contactParam mixes equal parameters of equal weights: uniform K, B, solimp over the fly's geoms
+      double tc = gsr.f(2 * g), dr = gsr.f(2 * g + 1), dmax = std::fmin(std::fmax(gsi.f(5 * g + 1), 1e-4), 0.9999), K, B;
+      if (tc > 0) { tc = std::fmax(tc, 2 * h); K = 1.0 / std::fmax(1e-15, dmax * dmax * tc * tc * dr * dr); B = 2.0 / std::fmax(1e-15, dmax * tc); }
+      else { K = -tc / std::fmax(1e-15, dmax * dmax); B = -dr / std::fmax(1e-15, dmax); }
+      if (g == 0) { V.c_K = static_cast<float>(K); V.c_B = static_cast<float>(B); for (int c = 0; c < 5; c++) V.c_solimp[c] = static_cast<float>(gsi.f(5 * g + c)); }
+      if (static_cast<float>(K) != V.c_K || static_cast<float>(B) != V.c_B) throw std::runtime_error("flight model: geom solref is expected to be uniform");
+      for (int c = 0; c < 5; c++) if (static_cast<float>(gsi.f(5 * g + c)) != V.c_solimp[c]) throw std::runtime_error("flight model: geom solimp is expected to be uniform");
+      if (gm.f(g) != 0) {
+        if (V.c_margin != 0.f && (V.c_margin != static_cast<float>(gm.f(g)) || V.c_gap != static_cast<float>(gg.f(g)))) throw std::runtime_error("flight model: one margin class expected");
+        V.c_margin = static_cast<float>(gm.f(g)); V.c_gap = static_cast<float>(gg.f(g));
+        V.cg_mmask[g >> 6] |= 1ull << (g & 63);
+      }
+    }
+    for (size_t k = 0; k < c1.count; k++) {
+      int g1 = c1.i(k), g2 = c2.i(k);
+      if (gt.i(g1) > gt.i(g2)) std::swap(g1, g2);  // mj: lower type code first
+      if (gl.i(g1) == gl.i(g2)) continue;            // (same link: welded together, filtered by mj_collision already)
+      cp_pair[V.ncp++] = static_cast<unsigned short>(g1 | (g2 << 8));
+    }
+  }
   // ---- pack ------------------------------------------------------------------------------------------
   set_off(V.d_link, A.put(d_link));
   set_off(V.d_madr, A.put(d_madr)); set_off(V.d_depth, A.put(d_depth));
@@ -569,6 +637,9 @@ inline HostModel build_host_model(const Blob &b) {
   set_off(V.wing_action, A.put(wing_action)); set_off(V.wing_ctrl, A.put(wing_ctrl));
   set_off(V.obsj_qadr, A.put(obsj_qadr)); set_off(V.obsj_dof, A.put(obsj_dof));
   set_off(V.qpos0, A.put(qpos0));
+  set_off(V.cg_link, A.put(cg_link)); set_off(V.cg_type, A.put(cg_type)); set_off(V.cg_pos, A.put(cg_pos)); set_off(V.cg_quat, A.put(cg_quat));
+  set_off(V.cg_size, A.put(cg_size)); set_off(V.cg_brad, A.put(cg_brad)); set_off(V.cg_invw, A.put(cg_invw));
+  set_off(V.cp_pair, A.put(cp_pair)); set_off(V.l_dofmask, A.put(l_dofmask));
   H.arena = A.bytes();
   return H;
 }

@@ -24,12 +24,17 @@
 #include "ball_env.hpp"
 #include "dev_model.hpp"
 #include "launch_order.hpp"
+#include "dev_math.hpp"
+#include "convex.hpp"
 
 #ifndef FFE_WAVES_PER_SIMD
 #define FFE_WAVES_PER_SIMD 4  // register budget = 512 / this; picked by measurement: with the LDS tile under 10 KB, 16 waves fit a CU
 #endif
 
 namespace ffe {
+
+constexpr int kMC = 6;   // contacts per env the solver carries (deepest kept; more is flagged)
+constexpr int kNSD = 8;  // convex pairs whose separating direction is remembered from substep to substep
 
 // ------------------------------------------------------------------------------------------------ state
 struct alignas(64) EnvState {
@@ -50,6 +55,12 @@ struct alignas(64) EnvState {
   unsigned long long in_lo_mask, in_hi_mask;  // limits instantiated but resolved inactive by the last substep's solve (first guess of the next)
   unsigned char cost_hist[32];  // solver iterations of the last control step that ended in each of 32 wing-beat phase bins (launch order)
   float s1_cdof[kMaxDof * 6], s1_buf[kMaxDof * 6], s1_f[kLanePad], s1_misc[16];
+  // contacts of the carried-over position stage (lane k = contact k) and the convex pairs' separating directions (flight_collide)
+  float ct_f[kMC][9];
+  int ct_i[kMC][3];
+  float sd_n[kNSD][3];
+  int sd_pid[kNSD];
+  int nct, sd_cnt, ct_pad[2];
 };
 
 struct TaskDev {
@@ -324,8 +335,15 @@ struct Ctx {
   float dinv[2];      // 1 / D of this lane's dof for the two resident factorisations
   unsigned la_pack;   // this lane's row start | depth << 10 | descendant count << 16 (read by every factor / solve)
   unsigned seq0, seq1, seq2, seq3;  // elimination order of the lane's branch, a byte per step (DevModel::br_seq)
+  // contacts of the current position stage: lane k < nct holds contact k (normal from geom1's link to geom2's, position relative to
+  // the root, distance, includemargin, sum of the two bodies' inverse weights, the two links, pair id)
+  float ct_nx, ct_ny, ct_nz, ct_px, ct_py, ct_pz, ct_dist, ct_incl, ct_invw;
+  int ct_l1, ct_l2, ct_pid, nct, ct_ovf;
+  // separating-direction cache of the convex pairs: lane k < sd_cnt holds an entry
+  float sd_nx, sd_ny, sd_nz;
+  int sd_pid, sd_cnt;
 #ifdef FFE_STAMPS
-  unsigned long long st_t0, st_acc[16];
+  unsigned long long st_t0, st_acc[20];
 #endif
 };
 
@@ -361,8 +379,8 @@ __device__ __forceinline__ const DevModel FFE_CONST &model(const Ctx &c) {
 // Diagnostic build only (-DFFE_STAMPS): per-section shader-clock shares, summed over waves (cdna guide section 7,
 // "In-kernel stamps").  The stamped build is never timed or shipped; read its SHARES, not its length.
 #ifdef FFE_STAMPS
-__device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[16] = {0}
+__device__ unsigned long long g_stamps[20];
+#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[20] = {0}
 #define STAMP(k)                                                   \
   do {                                                             \
     __builtin_amdgcn_s_waitcnt(0);                                 \
@@ -403,6 +421,162 @@ __device__ unsigned long long g_trace[32768][4];
 #define DBG(c, f) (0)
 #endif
 enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 << 18, DBG_SKIP_MENTRIES = 1 << 19, DBG_SKIP_GHOST = 1 << 20, DBG_SKIP_WBPG = 1 << 21, DBG_SKIP_OBS = 1 << 22, DBG_NO_CARRY = 1 << 23, DBG_NO_ORDER = 1 << 24 };
+
+// ------------------------------------------------------------------------------------------------ collision (flight)
+// ref: tasks/base.py:299-302 disables the floor contacts only; the fly's own geoms (legs welded to the thorax in their retracted
+// pose, head, mouth parts, wings, abdomen: fruitfly.xml:323-443, excludes :733-760) still collide in flight.  mj: mj_collision is part
+// of the position stage: `flight_collide` runs after stage 1 on the link frames it leaves (T.xpos / T.xmat + the link quaternions),
+// with the factor's workspace (T.LD) and the link scratch arrays (T.la .. T.lc) - both idle between stage 1 and stage 2 - as scratch.
+struct CollA { float4 gc[kMaxGeom], gq[kMaxGeom]; float lq[kMaxLink][4]; };                                        // over T.LD
+struct CollB { unsigned short cl1[128], cl2[32]; float rec[kMC][12]; float sdc[kNSD][4]; float sdn[kNSD][4]; float cl2n[32][4]; };  // over T.la .. T.lc
+static_assert(sizeof(CollA) <= sizeof(Tile::LD), "collision scratch A");
+static_assert(sizeof(CollB) <= sizeof(Tile::lT) + sizeof(Tile::lb) + sizeof(Tile::lc) && offsetof(Tile, lc) == offsetof(Tile, lT) + sizeof(Tile::lT) + sizeof(Tile::lb), "collision scratch B");
+__device__ __forceinline__ CollA &coll_a(Tile &T) { return *reinterpret_cast<CollA *>(&T.LD[0]); }
+__device__ __forceinline__ CollB &coll_b(Tile &T) { return *reinterpret_cast<CollB *>(&T.lT[0][0]); }
+
+__device__ __forceinline__ cvx::Geom load_geom(const CollA &A, const DevModel FFE_CONST &M, int g) {
+  const float4 cc = A.gc[g], qq = A.gq[g];
+  return cvx::Geom{dm::V3{cc.x, cc.y, cc.z}, dm::Q4{qq.x, qq.y, qq.z, qq.w}, M.cg_size[g], M.cg_size[kMaxGeom + g], M.cg_size[2 * kMaxGeom + g], M.cg_type[g]};
+}
+
+// Broad phase: MuJoCo's bounding-sphere test over the static candidate list, then a rigorous lower bound of the distance from a
+// separating direction (two generic ones, cvx::separation_bound, and the one the narrow phase found for the pair on the last
+// substep it ran: `sdc` in, `sdn` out).  Narrow phase: one lane per remaining pair (cvx::collide: mjc_CapsuleCapsule / the general
+// convex collider restated in convex.hpp).  A contact inside its margin but outside margin - gap exerts no force and - with no
+// adhesion actuator in the flight model - takes part in nothing: dropped.  The contacts (at most kMC, the deepest) are left in
+// `rec`.  Returns count | overflow << 8 | new cache count << 16.
+__device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CONST *Mp, const int lane, const int ncache) {
+  Tile &T = *Tp;
+  const DevModel FFE_CONST &M = *Mp;
+  CollA &A = coll_a(T);
+  CollB &B = coll_b(T);
+  const int ncg = M.ncg;
+  for (int g = lane; g < ncg; g += kWave) {
+    const int l = M.cg_link[g];
+    const float *lq = A.lq[l];
+    const dm::Q4 xq = {lq[0], lq[1], lq[2], lq[3]};
+    const dm::V3 gp = dm::V3{T.xpos[l][0], T.xpos[l][1], T.xpos[l][2]} + dm::qrot(xq, dm::V3{M.cg_pos[g], M.cg_pos[kMaxGeom + g], M.cg_pos[2 * kMaxGeom + g]});
+    const dm::Q4 gq = dm::qnormalize(dm::qmul(xq, dm::Q4{M.cg_quat[g], M.cg_quat[kMaxGeom + g], M.cg_quat[2 * kMaxGeom + g], M.cg_quat[3 * kMaxGeom + g]}));
+    A.gc[g] = make_float4(gp.x, gp.y, gp.z, M.cg_brad[g]);
+    A.gq[g] = make_float4(gq.w, gq.x, gq.y, gq.z);
+  }
+  SYNC();
+  const unsigned long long mm0 = M.cg_mmask[0], mm1 = M.cg_mmask[1];
+  const float mclass = M.c_margin;
+  auto pair_margin = [&](int a, int b) {
+    const bool ma = a < 64 ? ((mm0 >> a) & 1ull) : ((mm1 >> (a - 64)) & 1ull), mb = b < 64 ? ((mm0 >> b) & 1ull) : ((mm1 >> (b - 64)) & 1ull);
+    return (ma || mb) ? mclass : 0.f;
+  };
+  int n1 = 0, ovf = 0;
+  const int ncp = M.ncp;
+  for (int base = 0; base < ncp; base += kWave) {
+    const unsigned w = M.cp_pair[base + lane];
+    bool pass = false;
+    if (w != 0xffffu) {
+      const int a = w & 255, b = w >> 8;
+      const float4 ca = A.gc[a], cb = A.gc[b];
+      const float dx = cb.x - ca.x, dy = cb.y - ca.y, dz = cb.z - ca.z, reach = ca.w + cb.w + pair_margin(a, b);
+      pass = dx * dx + dy * dy + dz * dz <= reach * reach;
+    }
+    const unsigned long long bal = __ballot(pass);
+    const int idx = n1 + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pass && idx < 128) B.cl1[idx] = (unsigned short)w;
+    n1 += __popcll(bal);
+  }
+  if (n1 > 128) { n1 = 128; ovf = 1; }
+  SYNC();
+  int n2 = 0, nk = 0;
+#pragma unroll 1
+  for (int base = 0; base < n1; base += kWave) {
+    bool pass = false, keep = false, have_kn = false;
+    unsigned w = 0u;
+    dm::V3 kn = {0.f, 0.f, 0.f};
+    if (base + lane < n1) {
+      w = B.cl1[base + lane];
+      const int a = w & 255, b = w >> 8;
+      const cvx::Geom ga = load_geom(A, M, a), gb = load_geom(A, M, b);
+      const float margin = pair_margin(a, b), incl = margin - (margin != 0.f ? M.c_gap : 0.f);  // (only a contact inside margin - gap matters here)
+      pass = cvx::separation_bound(ga, gb) <= incl;
+      if (pass) {
+        for (int k = 0; k < ncache; k++) {
+          if (__float_as_int(B.sdc[k][3]) == (int)w) {
+            kn = dm::V3{B.sdc[k][0], B.sdc[k][1], B.sdc[k][2]};
+            keep = -cvx::overlap(ga, gb, kn) > incl;
+            have_kn = true;
+          }
+        }
+        pass = !keep;
+      }
+    }
+    const unsigned long long bal = __ballot(pass), balk = __ballot(keep);
+    const int idx = n2 + __popcll(bal & ((1ull << lane) - 1ull)), idk = nk + __popcll(balk & ((1ull << lane) - 1ull));
+    if (pass && idx < 32) { B.cl2[idx] = (unsigned short)w; float *o = B.cl2n[idx]; o[0] = kn.x; o[1] = kn.y; o[2] = kn.z; o[3] = have_kn ? 1.f : 0.f; }
+    if (keep && idk < kNSD) { B.sdn[idk][0] = kn.x; B.sdn[idk][1] = kn.y; B.sdn[idk][2] = kn.z; B.sdn[idk][3] = __int_as_float((int)w); }
+    n2 += __popcll(bal);
+    nk = min(nk + __popcll(balk), kNSD);
+  }
+  if (n2 > 32) { n2 = 32; ovf = 1; }
+  SYNC();
+  bool hit = false;
+  float dist = 0.f, margin = 0.f;
+  dm::V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
+  int a = 0, b = 0;
+  unsigned w = 0u;
+  if (lane < n2) {
+    w = B.cl2[lane];
+    a = w & 255; b = w >> 8;
+    margin = pair_margin(a, b);
+    const float *kn = B.cl2n[lane];
+    const cvx::Contact ct = cvx::collide(load_geom(A, M, a), load_geom(A, M, b), dm::V3{kn[0], kn[1], kn[2]}, kn[3] != 0.f);
+    dist = ct.dist; nrm = ct.n; cpos = ct.pos;
+    hit = dist < margin - (margin != 0.f ? M.c_gap : 0.f);  // (mj: dist <= margin is detected, dist < margin - gap is active; an inactive one takes part in nothing here)
+    if (nk + lane < kNSD) { float *o = B.sdn[nk + lane]; o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = __int_as_float((int)w); }
+  }
+  nk = min(nk + n2, kNSD);
+  unsigned long long bal = __ballot(hit);
+  if (__popcll(bal) > kMC) {  // more contacts than the solver carries: the env is flagged and the deepest are kept
+    ovf = 1;
+    int rank = 0;
+    for (unsigned long long m = bal; m; m &= m - 1) {
+      const int j = __ffsll((long long)m) - 1;
+      const float dj = __shfl(dist, j);
+      if (dj < dist || (dj == dist && j < lane)) rank++;
+    }
+    hit = hit && rank < kMC;
+    bal = __ballot(hit);
+  }
+  const int n = __popcll(bal), idx = __popcll(bal & ((1ull << lane) - 1ull));
+  if (hit) {
+    float *o = B.rec[idx];
+    o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = cpos.x; o[4] = cpos.y; o[5] = cpos.z; o[6] = dist;
+    o[7] = margin - (margin != 0.f ? M.c_gap : 0.f); o[8] = M.cg_invw[a] + M.cg_invw[b];
+    o[9] = __int_as_float(M.cg_link[a]); o[10] = __int_as_float(M.cg_link[b]); o[11] = __int_as_float((int)w);
+  }
+  SYNC();
+  return n | (ovf << 8) | (nk << 16);
+}
+
+// the position stage's collision: cache in, contacts + cache out (lane-resident, see Ctx)
+__device__ __forceinline__ void flight_collide(Ctx &c) {
+  const DevModel FFE_CONST &M = model(c);
+  Tile &T = c.T;
+  c.nct = 0;
+  if (M.ncg == 0 || (c.flags & FFE_NO_CONTACT)) return;
+  CollB &B = coll_b(T);
+  if (c.lane < kNSD) { float *o = B.sdc[c.lane]; o[0] = c.sd_nx; o[1] = c.sd_ny; o[2] = c.sd_nz; o[3] = __int_as_float(c.sd_pid); }
+  SYNC();
+  const int r = __builtin_amdgcn_readfirstlane(flight_collide_impl(&T, c.Mp, c.lane, c.sd_cnt));
+  c.nct = r & 0xff;
+  c.ct_ovf |= (r >> 8) & 0xff;
+  c.sd_cnt = r >> 16;
+  if (c.lane < kNSD) { const float *o = B.sdn[c.lane]; c.sd_nx = o[0]; c.sd_ny = o[1]; c.sd_nz = o[2]; c.sd_pid = __float_as_int(o[3]); }
+  if (c.lane < kMC) {
+    const float *o = B.rec[c.lane];
+    c.ct_nx = o[0]; c.ct_ny = o[1]; c.ct_nz = o[2]; c.ct_px = o[3]; c.ct_py = o[4]; c.ct_pz = o[5]; c.ct_dist = o[6]; c.ct_incl = o[7]; c.ct_invw = o[8];
+    c.ct_l1 = __float_as_int(o[9]); c.ct_l2 = __float_as_int(o[10]); c.ct_pid = __float_as_int(o[11]);
+  }
+  SYNC();
+}
 
 // Stage 1 = mj_fwdPosition + mj_fwdVelocity on the welded link model (mj_kinematics, mj_comPos, mj_crb,
 // mj_comVel, mj_passive, mj_rne).  Needs T.qpos / T.qvel; leaves cdof, cdofd, xpos, xmat, M, f_smooth_nb.
@@ -484,6 +658,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
     V3 p = kp;
     Q4 q = kq;
     q = qnormalize(q);
+    { float *lq = coll_a(T).lq[lane]; lq[0] = q.w; lq[1] = q.x; lq[2] = q.y; lq[3] = q.z; }  // (for flight_collide: the factor's workspace is idle in stage 1)
     xp = p;
     xm = q2m(q);
     mass = l_mass_;
@@ -929,28 +1104,136 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   int iters = 0;
   const bool want_euler = integrate && !(c.flags & FFE_NO_DAMPER);
   const float hB = (is_dof && want_euler) ? h * M.d_damp[lane] : 0.f;
-  if (ex_any == 0ULL) {
-    // no limit instantiated: one dual factorisation, one dual solve
+  // ---- contact rows of this position stage (mj: mj_makeConstraint for condim-1 contacts: one frictionless row each,
+  //      J = n . (jacp of geom2's body - jacp of geom1's at the contact point), mj_makeImpedance, mj_referenceConstraint).  The row is
+  //      kept by columns: this lane's dof entry of every contact's row in jk[]; lane k computes contact k's D and aref.
+  const int nct = c.nct;
+  float jk[kMC], cD = 0.f, car = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMC; k++) jk[k] = 0.f;
+  if (nct) {
+    const S6 cd = is_dof ? ld6(T.cdof[lane]) : zero6();
+    const V3 com = get_com(c);
+    float dmin = fminf(fmaxf(M.c_solimp[0], 1e-4f), 0.9999f), dmax = fminf(fmaxf(M.c_solimp[1], 1e-4f), 0.9999f), width = fmaxf(0.f, M.c_solimp[2]),
+          mid = fminf(fmaxf(M.c_solimp[3], 1e-4f), 0.9999f), power = fmaxf(1.f, M.c_solimp[4]);
+#pragma unroll
+    for (int k = 0; k < kMC; k++) {
+      if (k < nct) {
+        const V3 n = {rl_f(c.ct_nx, k), rl_f(c.ct_ny, k), rl_f(c.ct_nz, k)}, p = {rl_f(c.ct_px, k), rl_f(c.ct_py, k), rl_f(c.ct_pz, k)};
+        const unsigned long long m1 = M.l_dofmask[rl_i(c.ct_l1, k)], m2 = M.l_dofmask[rl_i(c.ct_l2, k)];
+        const int sg = (int)((m2 >> lane) & 1ULL) - (int)((m1 >> lane) & 1ULL);
+        if (is_dof && sg != 0) { const V3 u = lin(cd) + cross(ang(cd), p - com); jk[k] = (float)sg * dot(n, u); }
+        const float vel = wave_sum(jk[k] * qv);
+        if (lane == k) {
+          const float imp = impedance(dmin, dmax, width, mid, power, c.ct_dist, c.ct_incl);
+          cD = imp * __builtin_amdgcn_rcpf(fmaxf(1e-30f, (1.f - imp) * c.ct_invw));
+          car = -M.c_B * vel - M.c_K * imp * (c.ct_dist - c.ct_incl);
+        }
+      }
+    }
+  }
+  if (ex_any == 0ULL && nct == 0) {
+    // no limit instantiated, no contact: one dual factorisation, one dual solve
     bfactor<true>(c, 0.f, hB);
     if (want_euler) { const float2 r = bsolve<2>(c, f); a = r.x; ae = r.y; }
     else { a = bsolve<0>(c, f).x; ae = a; }
   } else {
+    // Contacts enter the same primal Newton through the matrix inversion lemma: with H0 = M + D_limits (the sparse factorisation) and
+    // the active contact rows J (m <= kMC of them), (H0 + J' D J) a = rhs + J' D aref is solved as
+    //   a = y0 + Y f,  y0 = H0^-1 rhs,  Y = H0^-1 J',  (D^-1 + J Y) f = -(J y0 - aref)      (f = the contacts' forces)
+    // i.e. m more triangular solves with the resident factor and an m x m system (rows on lanes 0 .. m-1, Gauss-Jordan by readlane).
+    // Y's columns live in LDS (T.crb / T.xmat[1..]: dead in stage 2) and are kept while the limit set - hence H0 - does not change.
+    bool cact = lane < nct;   // first guess: a contact inside its includemargin pushes
+    float cf = 0.f, y0 = 0.f;
+    unsigned ymask = 0u;
+    bool lim_changed = true;
+    auto yrow = [&](int k) -> float * { return k < 4 ? &T.crb[0][0] + kMaxDof * k : &T.xmat[1][0] + kMaxDof * (k - 4); };
+    static_assert(sizeof(T.crb) >= 4 * kMaxDof * 4 && sizeof(T.xmat) - 36 >= (kMC - 4) * kMaxDof * 4, "Y columns");
 #pragma unroll 1
     for (int it = 0; it < 8; it++) {
       const float add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
       const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
-      if (it == 0) bfactor<true>(c, add, hB);
-      else bfactor<false>(c, add, 0.f);
-      a = bsolve<0>(c, rhs).x;
+      if (lim_changed) {
+        if (it == 0) bfactor<true>(c, add, hB);
+        else bfactor<false>(c, add, 0.f);
+        y0 = bsolve<0>(c, rhs).x;
+        ymask = 0u;
+      }
+      a = y0;
+      const unsigned am = (unsigned)__ballot(cact) & ((1u << nct) - 1u);
+      if (am) {
+#pragma unroll
+        for (int k = 0; k < kMC; k++) {
+          if (((am >> k) & 1u) && !((ymask >> k) & 1u)) {
+            const float yk = bsolve<0>(c, jk[k]).x;
+            if (is_dof) yrow(k)[lane] = yk;
+            ymask |= 1u << k;
+          }
+        }
+        SYNC();
+        float srow[kMC], r = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMC; j++) srow[j] = lane == j ? 1.f : 0.f;   // (inactive rows stay identity: zero force)
+#pragma unroll
+        for (int i = 0; i < kMC; i++) {
+          if ((am >> i) & 1u) {
+            const float ri = wave_sum(jk[i] * y0);
+            if (lane == i) r = -(ri - car);
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+              if ((am >> j) & 1u) {
+                const float sv = wave_sum(jk[i] * (is_dof ? yrow(j)[lane] : 0.f));
+                if (lane == i) srow[j] = sv + (i == j ? __builtin_amdgcn_rcpf(fmaxf(cD, 1e-30f)) : 0.f);
+                if (lane == j && i != j) srow[i] = sv;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kMC; k++) {
+          if ((am >> k) & 1u) {
+            const float ipiv = 1.f / rl_f(srow[k], k), rk = rl_f(r, k);
+            float rowk[kMC];
+#pragma unroll
+            for (int j = 0; j < kMC; j++) rowk[j] = rl_f(srow[j], k);
+            if (lane != k && lane < kMC) {
+              const float fac = srow[k] * ipiv;
+#pragma unroll
+              for (int j = 0; j < kMC; j++) srow[j] -= fac * rowk[j];
+              r -= fac * rk;
+            }
+          }
+        }
+        float diag = srow[0];
+#pragma unroll
+        for (int j = 1; j < kMC; j++) diag = lane == j ? srow[j] : diag;
+        cf = (lane < kMC && ((am >> lane) & 1u)) ? r / diag : 0.f;
+#pragma unroll
+        for (int k = 0; k < kMC; k++)
+          if ((am >> k) & 1u) a += (is_dof ? yrow(k)[lane] : 0.f) * rl_f(cf, k);
+      } else cf = 0.f;
       iters++;
       const bool n_lo = ex_lo && (a - ar_lo < 0.f);
       const bool n_hi = ex_hi && (-a - ar_hi < 0.f);
-      const bool changed = (n_lo != act_lo) || (n_hi != act_hi);
-      act_lo = n_lo; act_hi = n_hi;
+      bool n_c = false;
+#pragma unroll
+      for (int k = 0; k < kMC; k++) {
+        if (k < nct) {
+          const float jar = wave_sum(jk[k] * a);
+          if (lane == k) n_c = jar - car < 0.f;
+        }
+      }
+      const bool lch = (n_lo != act_lo) || (n_hi != act_hi);
+      const bool changed = lch || (lane < nct && n_c != cact);
+      act_lo = n_lo; act_hi = n_hi; cact = n_c;
+      lim_changed = __ballot(lch) != 0ULL;
       if (__ballot(changed) == 0ULL) break;
     }
     if (act_lo) fc += D_lo * (ar_lo - a);
     if (act_hi) fc -= D_hi * (ar_hi + a);
+#pragma unroll
+    for (int k = 0; k < kMC; k++)
+      if (k < nct) fc += jk[k] * rl_f(cact ? cf : 0.f, k);
     ae = want_euler ? bsolve<1>(c, f + fc).y : a;
   }
   STAMP(14);  // (remaining glue inside the constraint/Euler block)
@@ -958,7 +1241,7 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   hi_mask = __ballot(act_hi);
   in_lo = __ballot(ex_lo && !act_lo);
   in_hi = __ballot(ex_hi && !act_hi);
-  iters_out = ex_any ? iters : 0;
+  iters_out = (ex_any || nct) ? iters : 0;
   c.qacc = a;
   // ---- accelerometer (mj: mj_rnePostConstraint + mj_objectAcceleration at the thorax site, which sits at the
   //      root-body origin): R^T (a_origin - g) with a_origin the free joint's linear acceleration
@@ -1170,9 +1453,11 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   Ctx c{Mp, T, lane, K.flags, 0.f, 0.f, {0.f, 0.f}, 0u, 0u, 0u, 0u, 0u};
 #ifdef FFE_STAMPS
   c.st_t0 = __builtin_amdgcn_s_memtime();
-  for (int k = 0; k < 16; k++) c.st_acc[k] = 0;
+  for (int k = 0; k < 20; k++) c.st_acc[k] = 0;
 #endif
   load_lane_consts(c);
+  if (lane < kNSD) { c.sd_nx = S.sd_n[lane][0]; c.sd_ny = S.sd_n[lane][1]; c.sd_nz = S.sd_n[lane][2]; c.sd_pid = S.sd_pid[lane]; }
+  c.sd_cnt = S.s1_valid ? S.sd_cnt : 0;
   float *obs = obs_out + (size_t)env * K.obs_dim;
   const bool phys_only = (mode == 2);
   const int nsub = phys_only ? nphys : M.nsub;
@@ -1322,10 +1607,16 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
         if (e < kMaxDof * 6) { (&T.cdof[0][0])[e] = pre_c[k]; (&T.buf[0][0])[e] = pre_b[k]; }
       }
       c.f_smooth_nb = pre_f;
+      if (lane < kMC) {  // the contacts of that position stage
+        const float *o = S.ct_f[lane];
+        c.ct_nx = o[0]; c.ct_ny = o[1]; c.ct_nz = o[2]; c.ct_px = o[3]; c.ct_py = o[4]; c.ct_pz = o[5]; c.ct_dist = o[6]; c.ct_incl = o[7]; c.ct_invw = o[8];
+        c.ct_l1 = S.ct_i[lane][0]; c.ct_l2 = S.ct_i[lane][1]; c.ct_pid = S.ct_i[lane][2];
+      }
+      c.nct = S.nct;
       if (lane < 9) T.xmat[0][lane] = pre_m;
       else if (lane < 12) T.sens[lane] = pre_m;  // CoM (see set_com)
       SYNC();
-    } else if (!DBG(c, DBG_SKIP_STAGE1) || s == 0) stage1(c);
+    } else if (!DBG(c, DBG_SKIP_STAGE1) || s == 0) { stage1(c); flight_collide(c); STAMP(16); }
     if (lane < 6 && (do_reset || s > 0)) {
       // buffered velocity sensors at the thorax site: gyro = body-frame angular velocity, velocimeter = R^T v
       float add;
@@ -1420,9 +1711,16 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   S.s1_f[lane] = c.f_smooth_nb;
   if (lane < 9) S.s1_misc[lane] = T.xmat[0][lane];
   if (lane == 0) { const V3 com_e = get_com(c); S.s1_misc[9] = com_e.x; S.s1_misc[10] = com_e.y; S.s1_misc[11] = com_e.z; S.s1_valid = 1; }
+  if (lane < kMC) {
+    float *o = S.ct_f[lane];
+    o[0] = c.ct_nx; o[1] = c.ct_ny; o[2] = c.ct_nz; o[3] = c.ct_px; o[4] = c.ct_py; o[5] = c.ct_pz; o[6] = c.ct_dist; o[7] = c.ct_incl; o[8] = c.ct_invw;
+    S.ct_i[lane][0] = c.ct_l1; S.ct_i[lane][1] = c.ct_l2; S.ct_i[lane][2] = c.ct_pid;
+  }
+  if (lane < kNSD) { S.sd_n[lane][0] = c.sd_nx; S.sd_n[lane][1] = c.sd_ny; S.sd_n[lane][2] = c.sd_nz; S.sd_pid[lane] = c.sd_pid; }
+  if (lane == 0) { S.nct = c.nct; S.sd_cnt = c.sd_cnt; S.ct_pad[0] = do_reset ? c.ct_ovf : (S.ct_pad[0] | c.ct_ovf); }
 #ifdef FFE_STAMPS
   STAMP(10);
-  if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);
+  if (lane == 0) for (int k = 0; k < 20; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);
 #endif
   TRACE_END(blockIdx.x, (unsigned)(iters & 0xff) | ((unsigned)(__popcll(lo_mask) + __popcll(hi_mask)) << 8) | ((unsigned)(tr_prev & 0xffff) << 16));  // this step's solver iterations, active limits at its end, the sort key it was launched with
 }
@@ -1458,7 +1756,7 @@ __global__ void get_task_state_kernel(const EnvState *states, int *ints, double 
   if (i >= batch) return;
   const EnvState &S = states[i];
   int *o = ints + (size_t)i * 8;
-  o[0] = S.wb_step; o[1] = S.wb_freq_idx; o[2] = S.step_counter; o[3] = S.traj_idx; o[4] = S.needs_reset; o[5] = S.nactive; o[6] = S.solver_iters; o[7] = 0;
+  o[0] = S.wb_step; o[1] = S.wb_freq_idx; o[2] = S.step_counter; o[3] = S.traj_idx; o[4] = S.needs_reset; o[5] = S.nactive; o[6] = S.solver_iters; o[7] = S.nct | (S.ct_pad[0] << 8);  // contacts of the current position stage | more than the solver carries (sticky over the episode)
   double *r = reals + (size_t)i * 8;
   r[0] = S.wb_ctrl_freq;
   for (int k = 0; k < 7; k++) r[1 + k] = S.ghost[k];
@@ -1831,8 +2129,8 @@ int ffe_time_kernel(ffe_handle h, const float *act, float *obs, float *rew, floa
 
 #ifdef FFE_STAMPS
 int ffe_debug_read_stamps(unsigned long long *out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 20 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[20] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 #endif

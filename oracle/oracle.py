@@ -143,6 +143,8 @@ def lib():
         L.fo_walk_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_walk_env_features.argtypes = [vp, dp, dp, dp, dp]
         L.fo_walk_env_reward_factors.argtypes = [vp, C.c_int, dp]
+        L.fo_data_deep_ratio.restype = C.c_double
+        L.fo_data_deep_ratio.argtypes = [vp, C.c_int]
         L.fo_env_counters.restype = C.c_int
         L.fo_env_counters.argtypes = [vp, ip, ip]
     return _lib
@@ -237,6 +239,11 @@ class OracleData:
         H = np.zeros((self.m.nv, self.m.nv)) if hessian else None
         cost = self.L.fo_debug_constraint_eval(self.m.ptr, self.ptr, _dp(jar), _dp(force), _dp(H) if hessian else None)
         return cost, force, H
+
+    def deep_ratio(self, reset=True):
+        """Deepest overlap of a convex pair since the last call, in units of the thinner geom's smallest semi-axis (a wing blade driven
+        through the abdomen by a stroke: past ~0.5 the direction of least overlap is no longer unique to float32 rounding)."""
+        return float(self.L.fo_data_deep_ratio(self.ptr, 1 if reset else 0))
 
     def contacts(self):
         """Rows: geom1, geom2, dim, exclude, efc_adr, dist, pos[3], normal[3], mu, friction, includemargin, normal force."""

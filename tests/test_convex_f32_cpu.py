@@ -67,7 +67,7 @@ BOUNDS = {
     "sphere-cylinder": (3e-7, 2e-6, 5e-7),
     "ellipsoid-ellipsoid": (4e-8, 6e-4, 3e-6),
     "ellipsoid-ellipsoid (thin wing)": (5e-7, 2e-3, 4e-4),  # a 0.0022 x 0.0175 x 0.114 blade flat on the thorax: the position along it is soft
-    "ellipsoid-cylinder": (5e-8, 1.5e-4, 1e-6),
+    "ellipsoid-cylinder": (5e-8, 1.5e-3, 8e-6),  # (the normal of an overlap across the cylinder's rim is found by the dual Newton: softer)
 }
 
 
