@@ -178,7 +178,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, **({} if fake else {"device_id": dev}))
 
-    from flybody_amd.distributed import TimestepGather, shard
+    from flybody_amd.distributed import ActionScatter, TimestepGather, shard
 
     B = args.envs_per_gpu
     env_id_base, _ = shard(rank, world, B)
@@ -198,7 +198,17 @@ def main():
         lo, hi = torch.full_like(lo, -0.2), torch.full_like(hi, 0.2)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     npool = 16
-    acts = [(lo + (hi - lo) * torch.rand(B, spec.shape[0], device=dev, generator=g)).contiguous() for _ in range(npool)]
+    # N = 1: the actions are this rank's own.  N > 1: the policy side sits on rank 0 - rank 0 draws the actions of
+    # all N * B envs and every rank receives its block through one scatter per step, issued one step ahead (double-buffered) so that
+    # it travels while the current step is simulated
+    nact = spec.shape[0]
+    rows = B * world if (world > 1 and rank == 0) else B
+    acts = [(lo + (hi - lo) * torch.rand(rows, nact, device=dev, generator=g)).contiguous() for _ in range(npool)] if (world == 1 or rank == 0) else None
+    scatters = [ActionScatter(B, nact, dev, world, rank) for _ in range(2)] if world > 1 else None
+    swork = [None, None]
+
+    def issue_scatter(k):
+        swork[k & 1] = scatters[k & 1](acts[k % npool] if rank == 0 else None, async_op=True)
 
     # The per-step gather of everything a central learner consumes: one RCCL call per step,
     # double-buffered so that the gather of step k travels over xGMI while step k+1 is being simulated.
@@ -206,7 +216,16 @@ def main():
     works = [None, None]
 
     def one_step(k):
-        ts = env.step(acts[k % npool])
+        if world > 1:
+            if swork[k & 1] is None:
+                issue_scatter(k)
+            swork[k & 1].wait()
+            swork[k & 1] = None
+            a = scatters[k & 1].local
+            issue_scatter(k + 1)
+        else:
+            a = acts[k % npool]
+        ts = env.step(a)
         if world > 1:
             i = k & 1
             if works[i] is not None:
@@ -219,6 +238,9 @@ def main():
             if works[i] is not None:
                 works[i].wait()
                 works[i] = None
+            if swork[i] is not None:
+                swork[i].wait()
+                swork[i] = None
 
     def sync():
         if not fake:
@@ -277,7 +299,8 @@ def main():
     # kernel trace reports for it); the timed region's own events also span the 6-12 us launch-order kernel that follows every step
     # (one launch per call, cycling through the same action pool as the timed region: same workload)
     nk = min(args.steps, 100)
-    k_ms = (sum(env.time_kernel(acts[k % npool], 1) for k in range(nk)) / nk) if hasattr(env, "time_kernel") else env.time_steps(acts[0], nk)
+    kacts = [acts[k % npool] for k in range(nk)] if world == 1 else [scatters[0].local] * nk  # (N > 1: the block last received)
+    k_ms = (sum(env.time_kernel(kacts[k], 1) for k in range(nk)) / nk) if hasattr(env, "time_kernel") else env.time_steps(kacts[0], nk)
     sync()
     k_ms_region = ev0.elapsed_time(ev1) / args.steps if ev0 is not None else k_ms
 

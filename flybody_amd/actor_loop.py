@@ -41,8 +41,16 @@ class NStepTransitionWriter:
     def observe(self, action, timestep, flat_observation):
         t = self._t
         st = timestep.step_type
-        assert action.is_cuda and action.dtype == t.float32 and action.is_contiguous() and tuple(action.shape) == (self.batch_size, self.act_dim)
-        assert flat_observation.is_contiguous() and tuple(flat_observation.shape) == (self.batch_size, self.obs_dim)
+        # the C ABI takes raw device pointers: everything it will read is checked here (a float64 reward, a strided view or a host
+        # tensor would otherwise be read as garbage, or fault)
+        def ok(x, dtype, shape):
+            return x.is_cuda and x.device == self.device and x.dtype == dtype and x.is_contiguous() and tuple(x.shape) == shape
+
+        B = self.batch_size
+        assert ok(action, t.float32, (B, self.act_dim)), "action: float32 [B, A] contiguous on the writer's device"
+        assert ok(flat_observation, t.float32, (B, self.obs_dim)), "flat_observation: float32 [B, O] contiguous on the writer's device"
+        assert ok(st, t.int32, (B,)) and ok(timestep.reward, t.float32, (B,)) and ok(timestep.discount, t.float32, (B,)), \
+            "step_type int32 [B], reward / discount float32 [B], contiguous on the writer's device"
         stream = C.c_void_p(t.cuda.current_stream(self.device).cuda_stream)
         rc = self._L.ffe_nstep_observe(self._h, action.data_ptr(), st.data_ptr(), timestep.reward.data_ptr(), timestep.discount.data_ptr(),
                                        flat_observation.data_ptr(), stream)
@@ -73,7 +81,9 @@ class NStepTransitionWriter:
         return t.as_tensor(_Mem(), device=self.device)
 
     def transitions(self):
-        """(obs [N,O], action [N,A], n_step_return [N], discount [N], next_obs [N,O]) views of the N = min(written, capacity) filled slots."""
+        """(obs [N,O], action [N,A], n_step_return [N], discount [N], next_obs [N,O]) views of the N = min(written, capacity) filled slots.
+        Slots are claimed before their rows are stored: a reader must be stream-ordered after the last `observe` (this method
+        synchronises the device through `num_written`); after the ring has wrapped the slots are in no particular age order."""
         t, n = self._t, min(self.num_written(), self.capacity)
         o = self._view(self._ptr[0], (self.capacity, self.obs_dim), t.float32)[:n]
         a = self._view(self._ptr[1], (self.capacity, self.act_dim), t.float32)[:n]
@@ -122,8 +132,9 @@ class BatchedActorLoop:
         if self.adder is not None:
             self.adder.observe(action, ts, self.env.flat_observation)
         # per-env return / length and the totals of finished episodes: one fused launch (ffe_episode_stats)
-        rc = self._L.ffe_episode_stats(ts.step_type.data_ptr(), ts.reward.data_ptr(), self._ret.data_ptr(), self._len.data_ptr(), self._tot.data_ptr(),
-                                       self._sum_ret.data_ptr(), self.env.batch_size, C.c_void_p(t.cuda.current_stream(self.env.device).cuda_stream))
+        with t.cuda.device(self.env.device):  # (ffe_episode_stats launches on the current device: make it the env's)
+            rc = self._L.ffe_episode_stats(ts.step_type.data_ptr(), ts.reward.data_ptr(), self._ret.data_ptr(), self._len.data_ptr(), self._tot.data_ptr(),
+                                           self._sum_ret.data_ptr(), self.env.batch_size, C.c_void_p(t.cuda.current_stream(self.env.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("ffe_episode_stats failed")
 

@@ -5,10 +5,12 @@
 //
 // Per env and per observed step t (action a_t, next timestep (r, d, o_{t+1}, step_type)):
 //   * the ring keeps the last n entries (o_s, a_s, r_{s+1}, d_{s+1});
-//   * once n entries are held, the transition starting n steps back is written:
-//       (o_s, a_s, R, D, o_{t+1}),  R = r_0 + g d_0 r_1 + g^2 d_0 d_1 r_2 + ...,  D = g^(n-1) d_0 d_1 ... d_(n-1)
+//   * every observed step writes the transition from the OLDEST held entry to o_{t+1} - acme's _write runs on every add() and does
+//     not wait for n entries, so an episode's first n - 1 steps yield the short transitions (o_0 -> o_1), (o_0 -> o_2), ...:
+//       (o_s, a_s, R, D, o_{t+1}),  R = r_0 + g d_0 r_1 + g^2 d_0 d_1 r_2 + ...,  D = g^(m-1) d_0 d_1 ... d_(m-1)   (m entries spanned)
 //     (acme's _compute_cumulative_quantities: the env discounts multiply in, the learner applies one more g);
-//   * on LAST the remaining, shorter, transitions are flushed as well (acme's _write_last), all ending in o_{t+1};
+//   * on LAST the remaining, shorter, transitions are flushed as well (acme's _write_last), all ending in o_{t+1}: an episode of
+//     T < n steps leaves 2 T - 1 transitions, one of T >= n steps leaves T + n - 1;
 //   * FIRST starts a new episode: the ring is cleared and o_0 stored.
 // One wavefront per env: lanes move the observation / action rows (coalesced), lane-parallel products give R and D.
 // Transitions land in a device-resident replay ring (slot = running counter mod capacity); nothing touches the host.
@@ -85,9 +87,9 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void nstep_observe_kernel(Dev D
     head = D.head[env]; cnt = D.count[env];
     head_new = (head + 1) % n; cnt_new = cnt < n ? cnt + 1 : n;
     first = (head_new - cnt_new + n) % n;  // ring index of the oldest held entry after this append
-    // how many transitions this call writes: the full-length one (if n entries are held) and, on LAST, every shorter tail
-    const int n_full = cnt_new == n ? 1 : 0;
-    total = n_full + (st == FFE_STEP_LAST ? cnt_new - n_full : 0);
+    // how many transitions this call writes: the one from the oldest held entry (n steps long once the ring is full, shorter during
+    // an episode's first steps) and, on LAST, every shorter tail
+    total = 1 + (st == FFE_STEP_LAST ? cnt_new - 1 : 0);
   }
   if (lane == 0) s_total[wave] = total;
   __syncthreads();
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void nstep_observe_kernel(Dev D
   if (total > 0) {
     unsigned long long base = s_base;
     for (int w = 0; w < wave; w++) base += (unsigned long long)s_total[w];
-    for (int j = 0; j < total; j++)  // j = 0 is the oldest start; with a full ring that is the n-step transition, the rest (LAST only) start later
+    for (int j = 0; j < total; j++)  // j = 0 starts at the oldest held entry (the n-step transition once the ring is full), the rest (LAST only) start later
       emit(D, env, lane, first, j, cnt_new, o_next, (base + j) % (unsigned long long)D.capacity, rew_l, disc_l, in_lanes);
   }
   for (int k = lane; k < O; k += 64) lo[k] = o_next[k];

@@ -174,8 +174,10 @@ const char *ffe_version(void);
  * Replaces acme.adders.reverb.NStepTransitionAdder(n_step, discount) as built at agents/ray_distributed_dmpo.py:514-521
  * (n_step = 50, train_dmpo_ray.py:236) and driven through actor.observe_first / actor.observe (agents/actors.py:91-101).
  * One call per env step with the action that was applied and the timestep ffe_step returned; FIRST rows start an episode
- * (their action is ignored).  Per env, once n entries are held each call writes (o_t-n+1, a_t-n+1, R, D, o_t+1) with
- * R = r_0 + g d_0 r_1 + g^2 d_0 d_1 r_2 + ... and D = g^(n-1) d_0 ... d_(n-1); LAST also flushes the shorter tails.
+ * (their action is ignored).  Per env each call writes the transition from the oldest held entry (at most n steps back) to the
+ * new observation, (o_s, a_s, R, D, o_t+1) with R = r_0 + g d_0 r_1 + g^2 d_0 d_1 r_2 + ... and D = g^(m-1) d_0 ... d_(m-1) over the
+ * m <= n entries spanned - like acme's adder it does not wait for n entries, so an episode's first n - 1 steps yield the short
+ * transitions (o_0 -> o_1), (o_0 -> o_2), ...; LAST also flushes the shorter tails (an episode of T steps leaves T + min(T, n) - 1).
  * Transitions go to a device replay ring of `capacity` slots (slot = count mod capacity).  acme is not in the reference tree:
  * these semantics restate its published behaviour (parity unpinned, tests/test_nstep.py). */
 typedef struct ffe_nstep *ffe_nstep_handle;

@@ -16,7 +16,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    from flybody_amd.distributed import TimestepGather, shard
+    from flybody_amd.distributed import ActionScatter, TimestepGather, shard
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,6 +41,16 @@ def _worker(rank, world, port, q):
             ok &= torch.equal(uo, o) and torch.equal(ur, rw) and torch.equal(ud, dc) and torch.equal(us, s)
     else:
         ok = out is None
+    # the action path: rank 0 holds every env's action, each rank receives its contiguous block (blocking and asynchronous)
+    A = 12
+    ga = torch.Generator().manual_seed(7)
+    all_actions = torch.rand(world * B, A, generator=ga)
+    sc = ActionScatter(B, A, "cpu", world, rank)
+    mine = sc(all_actions if rank == 0 else None)
+    ok &= torch.equal(mine, all_actions[rank * B:(rank + 1) * B])
+    w = sc((2 * all_actions) if rank == 0 else None, async_op=True)
+    w.wait()
+    ok &= torch.equal(sc.local, 2 * all_actions[rank * B:(rank + 1) * B])
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -18,11 +18,11 @@ def _reference(obs, act, rew, disc, st, n, gamma):
             continue
         hist.append((last, act[t], np.float32(rew[t]), np.float32(disc[t])))
         hist = hist[-n:]
-        starts = []
-        if len(hist) == n:
-            starts.append(0)
+        # acme's NStepTransitionAdder._write runs on every add() and does not wait for n entries: during an episode's first n - 1
+        # steps it writes the short transitions (o_0 -> o_1), (o_0 -> o_2), ...; _write_last then flushes the tails
+        starts = [0]
         if st[t] == 2:
-            starts += list(range(1 if len(hist) == n else 0, len(hist)))
+            starts += list(range(1, len(hist)))
         for s in starts:
             ret, td = hist[s][2], hist[s][3]
             for i in range(s + 1, len(hist)):
