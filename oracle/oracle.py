@@ -143,6 +143,8 @@ def lib():
         L.fo_walk_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_walk_env_features.argtypes = [vp, dp, dp, dp, dp]
         L.fo_walk_env_reward_factors.argtypes = [vp, C.c_int, dp]
+        L.fo_data_contact_hist.restype = C.c_int
+        L.fo_data_contact_hist.argtypes = [vp, ip, dp, C.c_int]
         L.fo_data_deep_ratio.restype = C.c_double
         L.fo_data_deep_ratio.argtypes = [vp, C.c_int]
         L.fo_env_counters.restype = C.c_int
@@ -239,6 +241,12 @@ class OracleData:
         H = np.zeros((self.m.nv, self.m.nv)) if hessian else None
         cost = self.L.fo_debug_constraint_eval(self.m.ptr, self.ptr, _dp(jar), _dp(force), _dp(H) if hessian else None)
         return cost, force, H
+
+    def contact_hist(self, reset=True):
+        """(active contacts each substep used, closest approach of any candidate pair to a switching distance) since the last reset."""
+        counts, gap = np.zeros(16, dtype=np.int32), C.c_double(0)
+        n = self.L.fo_data_contact_hist(self.ptr, _ip(counts), C.byref(gap), 1 if reset else 0)
+        return counts[:n].copy(), float(gap.value)
 
     def deep_ratio(self, reset=True):
         """Deepest overlap of a convex pair since the last call, in units of the thinner geom's smallest semi-axis (a wing blade driven
