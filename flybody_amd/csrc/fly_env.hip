@@ -1717,7 +1717,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     S.ct_i[lane][0] = c.ct_l1; S.ct_i[lane][1] = c.ct_l2; S.ct_i[lane][2] = c.ct_pid;
   }
   if (lane < kNSD) { S.sd_n[lane][0] = c.sd_nx; S.sd_n[lane][1] = c.sd_ny; S.sd_n[lane][2] = c.sd_nz; S.sd_pid[lane] = c.sd_pid; }
-  if (lane == 0) { S.nct = c.nct; S.sd_cnt = c.sd_cnt; S.ct_pad[0] = do_reset ? c.ct_ovf : (S.ct_pad[0] | c.ct_ovf); S.ct_pad[1] = T.park_i[5]; }
+  if (lane == 0) { S.nct = c.nct; S.sd_cnt = c.sd_cnt; S.ct_pad[0] = c.ct_ovf; S.ct_pad[1] = T.park_i[5]; }
 #ifdef FFE_STAMPS
   STAMP(10);
   if (lane == 0) for (int k = 0; k < 20; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);
@@ -1756,7 +1756,7 @@ __global__ void get_task_state_kernel(const EnvState *states, int *ints, double 
   if (i >= batch) return;
   const EnvState &S = states[i];
   int *o = ints + (size_t)i * 8;
-  o[0] = S.wb_step; o[1] = S.wb_freq_idx; o[2] = S.step_counter; o[3] = S.traj_idx; o[4] = S.needs_reset; o[5] = S.nactive; o[6] = S.solver_iters; o[7] = S.nct | ((S.ct_pad[0] & 255) << 8) | (S.ct_pad[1] << 16);  // contacts of the current position stage | more than the solver carries (sticky over the episode) | contacts each of the last step's substeps used, 4 bits each
+  o[0] = S.wb_step; o[1] = S.wb_freq_idx; o[2] = S.step_counter; o[3] = S.traj_idx; o[4] = S.needs_reset; o[5] = S.nactive; o[6] = S.solver_iters; o[7] = S.nct | ((S.ct_pad[0] & 255) << 8) | (S.ct_pad[1] << 16);  // contacts of the current position stage | some position stage of the last step met more contacts than the solver carries (the deepest kMC were kept) | contacts each of the last step's substeps used, 4 bits each
   double *r = reals + (size_t)i * 8;
   r[0] = S.wb_ctrl_freq;
   for (int k = 0; k < 7; k++) r[1 + k] = S.ghost[k];

@@ -18,7 +18,7 @@ from flybody_amd.tasks.wbpg import build_tables  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 names = json.load(open(BLOB.replace(".ffmb", ".json")))["geom_name"]
-B, STEPS, DEEP = 192, 300, float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
+B, STEPS, DEEP = 256, 500, float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 env = fly_envs.flight_imitation(batch_size=B, random_state=0)
 rq, rv = preprocess(*flight_trajectories())
 om = O.OracleModel(BLOB)
@@ -27,7 +27,7 @@ oenvs = [O.OracleFlightEnv(om, tables, rq, rv, ghost_accel_z=env.ghost_accel_z, 
 lo = torch.tensor(env.action_spec().minimum, device="cuda"); hi = torch.tensor(env.action_spec().maximum, device="cuda")
 g = torch.Generator(device="cuda").manual_seed(77)
 env.reset(); [e.reset() for e in oenvs]
-alive = np.ones(B, bool); deep_prev = np.zeros(B); nbad = deep = comp = nflip = nflip_bad = 0; flipgaps = []
+alive = np.ones(B, bool); deep_prev = np.zeros(B); nbad = deep = comp = nflip = nflip_bad = nover = 0; flipgaps = []
 hist = []
 for k in range(STEPS):
     a = (lo + (hi - lo) * torch.rand(B, 12, device="cuda", generator=g)).contiguous()
@@ -51,6 +51,8 @@ for k in range(STEPS):
             continue
         if dr > DEEP:
             deep += 1; resync.append(j); continue
+        if (int(ints[j, 7]) >> 8) & 255:
+            nover += 1; resync.append(j); continue
         comp += 1
         e = abs(float(rew[j]) - orr)
         if flip:
@@ -71,6 +73,7 @@ for k in range(STEPS):
         env.set_state(qpos, qvel)
 h = np.array(hist)
 print(f"contact flips {nflip} (of them reward err > 1e-4: {nflip_bad}); oracle switching gaps on flips: max {max(flipgaps, default=0):.2e} median {np.median(flipgaps) if flipgaps else 0:.2e}")
+print(f"over {nover}")
 print(f"compared {comp}, deep {deep}, dropped {int((~alive).sum())}; reward err > 1e-4: {(h[:,0] > 1e-4).sum()}, > 1e-5: {(h[:,0] > 1e-5).sum()}, max {h[:,0].max():.2e}")
 for lo_, hi_ in ((0, 0.1), (0.1, 0.2), (0.2, 0.3), (0.3, 0.4), (0.4, 0.5), (0.5, 1.0)):
     m = (h[:, 1] >= lo_) & (h[:, 1] < hi_)
