@@ -60,7 +60,7 @@ struct alignas(16) BState {
   int step_counter, needs_reset, overflow, iters, ncon, have_ws, nself, pad1;
   unsigned con_hist[2];  // active (inside includemargin) contacts of each of the control step's first 16 substeps, 4 bits each: parity tooling
   unsigned det_hist[2];  // detected (inside margin) contacts of its first 12 substeps, 5 bits each
-  float sd_n[NSD][3];    // separating-direction cache of the convex pairs (convex_collide)
+  float sd_n[NSD][4];    // separating-direction cache of the convex pairs (convex_collide)
   unsigned short sd_pid[NSD];
   int sd_cnt, ws_n, pad2[2];
   float ws_f[NC];        // forces of the fly-fly contacts of the last substep, by pair id (warm start)
@@ -89,7 +89,7 @@ struct alignas(16) BTile {
           union {
             float F[NDP][6];                // crb * cdof during the inertia assembly
             float lk[NL][12];               // link exchange of the tree passes: pose (7) | motion vector (6) | crb (10) | force (6)
-            struct { float pg[NPG * 9]; unsigned short cl1[CL1], cl2[64], tc_pid[NSD]; float tc_n[NSD][3]; };  // collision: primitive geom slots, pair lists, next cache
+            struct { float pg[NPG * 9]; unsigned short cl1[CL1], cl2[CL2], tc_pid[NSD]; float tc_n[NSD][4], cl2n[CL2][5]; };  // collision: primitive geom slots, pair lists, next cache
           };
         };
         float G[RMAX * (RMAX + 1) / 2];     // stage 2: G = J M^-1 J' over the constraint rows, lower triangle packed by rows (lane r owns row r)
@@ -115,7 +115,7 @@ struct alignas(16) BTile {
   unsigned char r_blk[RMAX], r_col[RMAX], r_dof[RMAX], rowof[NBLK][KCOL];
   float sens[24];  // running sums of the buffered sensors: force 18, touch 6
   // separating directions of the convex pairs that reached the narrow phase, kept from substep to substep (convex_collide)
-  float sd_n[NSD][3];
+  float sd_n[NSD][4];  // direction | the capsule's axis parameter of a capsule - convex pair
   unsigned short sd_pid[NSD];
   int sd_cnt;
   // fly-fly contacts: pair id of each slot, and the pairs' forces of the last substep (warm start of their rows)
@@ -608,20 +608,29 @@ __device__ __noinline__ int convex_collide(BTile *Tp, ModelPtr Mp, const int lan
   const int ncache = T.sd_cnt;
 #pragma unroll 1
   for (int base = 0; base < n1; base += 64) {
-    bool pass = false, keep = false;
+    bool pass = false, keep = false, have_kn = false;
     unsigned w = 0u;
     V3 kn = {0.f, 0.f, 0.f};
+    float kt = 0.f;
     if (base + lane < n1) {
       w = T.cl1[base + lane];
       const int a = w & 255, b = w >> 8;
       const cvx::Geom ga = load_geom(T, M, a), gb = load_geom(T, M, b);
-      const float margin = pair_margin(a, b);
-      pass = cvx::separation_bound(ga, gb) <= margin;
+      // the distance that matters: the margin where an adhesion actuator shares its pull over every detected contact of its body,
+      // margin - gap (a contact beyond it exerts no force and gets no slot) otherwise
+      float thr = pair_margin(a, b);
+      {
+        const int la_ = M.cg_link[a], lb_ = M.cg_link[b];
+        if ((la_ < 0 || M.l_adh[la_] < 0) && (lb_ < 0 || M.l_adh[lb_] < 0) && thr != 0.f) thr -= M.sc_gap;
+      }
+      pass = cvx::separation_bound(ga, gb) <= thr;
       if (pass) {
         for (int k = 0; k < ncache; k++) {
           if (T.sd_pid[k] == w) {
             kn = V3{T.sd_n[k][0], T.sd_n[k][1], T.sd_n[k][2]};
-            keep = -cvx::overlap(ga, gb, kn) > margin;
+            kt = T.sd_n[k][3];
+            keep = -cvx::overlap(ga, gb, kn) > thr;
+            have_kn = true;
           }
         }
         pass = !keep;
@@ -629,26 +638,27 @@ __device__ __noinline__ int convex_collide(BTile *Tp, ModelPtr Mp, const int lan
     }
     const unsigned long long bal = __ballot(pass), balk = __ballot(keep);
     const int idx = n2 + __popcll(bal & ((1ull << lane) - 1ull)), idk = nk + __popcll(balk & ((1ull << lane) - 1ull));
-    if (pass && idx < 64) T.cl2[idx] = (unsigned short)w;
-    if (keep && idk < NSD) { T.tc_pid[idk] = (unsigned short)w; T.tc_n[idk][0] = kn.x; T.tc_n[idk][1] = kn.y; T.tc_n[idk][2] = kn.z; }
+    if (pass && idx < CL2) { T.cl2[idx] = (unsigned short)w; float *o = T.cl2n[idx]; o[0] = kn.x; o[1] = kn.y; o[2] = kn.z; o[3] = have_kn ? 1.f : 0.f; o[4] = kt; }
+    if (keep && idk < NSD) { T.tc_pid[idk] = (unsigned short)w; T.tc_n[idk][0] = kn.x; T.tc_n[idk][1] = kn.y; T.tc_n[idk][2] = kn.z; T.tc_n[idk][3] = kt; }
     n2 += __popcll(bal);
     nk = min(nk + __popcll(balk), NSD);
   }
-  if (n2 > 64) { n2 = 64; ovf = 1; }
+  if (n2 > CL2) { n2 = CL2; ovf = 1; }
 #ifdef CVXDBG_NO_NARROW
   n2 = 0;
 #endif
   DM_SYNC();
   bool hit = false, dropped = false;
-  float dist = 0.f, margin = 0.f;
+  float dist = 0.f, margin = 0.f, ctt = 0.f;
   V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
   int a = 0, b = 0;
   if (lane < n2) {
     const unsigned w = T.cl2[lane];
     a = w & 255; b = w >> 8;
     margin = pair_margin(a, b);
-    const cvx::Contact ct = cvx::collide(load_geom(T, M, a), load_geom(T, M, b));
-    dist = ct.dist; nrm = ct.n; cpos = ct.pos;
+    const float *kn = T.cl2n[lane];
+    const cvx::Contact ct = cvx::collide(load_geom(T, M, a), load_geom(T, M, b), V3{kn[0], kn[1], kn[2]}, kn[3] != 0.f, kn[4]);
+    dist = ct.dist; nrm = ct.n; cpos = ct.pos; ctt = ct.t;
     hit = dist <= margin;
     // (an inactive contact no adhesion actuator takes part in gets no slot: see self_collide)
     if (hit && dist >= margin - (margin != 0.f ? M.sc_gap : 0.f)) {
@@ -657,12 +667,12 @@ __device__ __noinline__ int convex_collide(BTile *Tp, ModelPtr Mp, const int lan
       hit = !dropped;
     }
     if (nk + lane < NSD) {  // its direction, for the next substep's second test
-      T.tc_pid[nk + lane] = (unsigned short)w; T.tc_n[nk + lane][0] = nrm.x; T.tc_n[nk + lane][1] = nrm.y; T.tc_n[nk + lane][2] = nrm.z;
+      T.tc_pid[nk + lane] = (unsigned short)w; T.tc_n[nk + lane][0] = nrm.x; T.tc_n[nk + lane][1] = nrm.y; T.tc_n[nk + lane][2] = nrm.z; T.tc_n[nk + lane][3] = ctt;
     }
   }
   nk = min(nk + n2, NSD);
   DM_SYNC();
-  if (lane < nk) { T.sd_pid[lane] = T.tc_pid[lane]; T.sd_n[lane][0] = T.tc_n[lane][0]; T.sd_n[lane][1] = T.tc_n[lane][1]; T.sd_n[lane][2] = T.tc_n[lane][2]; }
+  if (lane < nk) { T.sd_pid[lane] = T.tc_pid[lane]; T.sd_n[lane][0] = T.tc_n[lane][0]; T.sd_n[lane][1] = T.tc_n[lane][1]; T.sd_n[lane][2] = T.tc_n[lane][2]; T.sd_n[lane][3] = T.tc_n[lane][3]; }
   if (lane == 0) T.sd_cnt = nk;
   const unsigned long long bal = __ballot(hit);
   const int n = __popcll(bal), idx = nprev + __popcll(bal & ((1ull << lane) - 1ull));
@@ -1945,7 +1955,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     if (!phys_only) step_counter++;
   }
   if (lane < 24) T.sens[lane] = 0.f;
-  if (lane < NSD) { T.sd_pid[lane] = S.sd_pid[lane]; T.sd_n[lane][0] = S.sd_n[lane][0]; T.sd_n[lane][1] = S.sd_n[lane][1]; T.sd_n[lane][2] = S.sd_n[lane][2]; }
+  if (lane < NSD) { T.sd_pid[lane] = S.sd_pid[lane]; T.sd_n[lane][0] = S.sd_n[lane][0]; T.sd_n[lane][1] = S.sd_n[lane][1]; T.sd_n[lane][2] = S.sd_n[lane][2]; T.sd_n[lane][3] = S.sd_n[lane][3]; }
   if (lane == 0) { T.sd_cnt = do_reset ? 0 : S.sd_cnt; T.ws_n = do_reset ? 0 : S.ws_n; }
   if (lane < NC) { T.ws_pid[lane] = S.ws_pid[lane]; T.ws_f[lane] = S.ws_f[lane]; }
   DM_SYNC();
@@ -1960,7 +1970,7 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
     stage1(c);
     if (!do_reset && s == nsub) break;
     if (s < 16) con_hist |= (unsigned long long)min(c.nact, 15) << (4 * s);
-    if (s < 12) det_hist |= (unsigned long long)min(c.nc + c.nsc + c.ndrop, 31) << (5 * s);
+    if (s < 12) det_hist |= (unsigned long long)min(c.nc + c.nsc, 31) << (5 * s);
     float act_new;
     stage2(c, act_reg, ctrl_reg, act_new, !do_reset, iters, &qn2);
     if (do_reset) break;
@@ -1973,13 +1983,13 @@ __global__ __launch_bounds__(64, 2) void ball_step_kernel(const BallModel *__res
 #pragma unroll
   for (int s = 0; s < 3; s++) S.wsc[lane][s] = c.wsc[s];
   if (lane < NU) S.act[lane] = do_reset ? 0.f : act_reg;
-  if (lane < NSD) { S.sd_pid[lane] = T.sd_pid[lane]; S.sd_n[lane][0] = T.sd_n[lane][0]; S.sd_n[lane][1] = T.sd_n[lane][1]; S.sd_n[lane][2] = T.sd_n[lane][2]; }
+  if (lane < NSD) { S.sd_pid[lane] = T.sd_pid[lane]; S.sd_n[lane][0] = T.sd_n[lane][0]; S.sd_n[lane][1] = T.sd_n[lane][1]; S.sd_n[lane][2] = T.sd_n[lane][2]; S.sd_n[lane][3] = T.sd_n[lane][3]; }
   if (lane == 0) { S.sd_cnt = T.sd_cnt; S.ws_n = T.ws_n; }
   if (lane < NC) { S.ws_pid[lane] = T.ws_pid[lane]; S.ws_f[lane] = T.ws_f[lane]; }
   if (lane == 0) {
     S.ballq[0] = c.bq.w; S.ballq[1] = c.bq.x; S.ballq[2] = c.bq.y; S.ballq[3] = c.bq.z;
     S.ballw[0] = c.bw.x; S.ballw[1] = c.bw.y; S.ballw[2] = c.bw.z;
-    S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc + c.nsc + c.ndrop; S.nself = c.nsc + c.ndrop;
+    S.step_counter = step_counter; S.iters = iters; S.ncon = c.nc + c.nsc; S.nself = c.nsc;  // (contacts that take part in something: an inactive one without an adhesion actuator on either body is not kept)
     S.con_hist[0] = (unsigned)con_hist; S.con_hist[1] = (unsigned)(con_hist >> 32);
     S.det_hist[0] = (unsigned)det_hist; S.det_hist[1] = (unsigned)(det_hist >> 32);
     // key of the next launch's order: what a wave's lifetime varies with - Newton iterations over the step's substeps (4 us each)

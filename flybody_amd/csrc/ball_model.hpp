@@ -37,9 +37,14 @@ constexpr int NMMAX = 584;  // M entries (580) padded
 constexpr int ECAP = 10;    // M entries per lane
 constexpr int NSTEP = 14;   // pivots per block (largest block: abdomen / head tree, 14 dofs)
 constexpr int NBLK = 12;    // independent blocks of M (6 legs, head tree, abdomen, 2 wings, 2 halteres)
-constexpr int NC = 16;      // contact capacity per env, ball and fly-fly contacts together (overflow is flagged)
-constexpr int RMAX = 48;    // constraint rows per env: 3 per ball contact + 1 per fly-fly contact + instantiated joint limits (overflow is flagged)
-constexpr int KCOL = 24;    // solve columns per block of M = constraint rows one block can carry (a leg at saturated actions: 5 ball contacts + limits)
+#ifndef FFB_NC
+#define FFB_NC 16
+#define FFB_RMAX 48
+#define FFB_KCOL 24
+#endif
+constexpr int NC = FFB_NC;      // contact capacity per env, ball and fly-fly contacts together (overflow is flagged)
+constexpr int RMAX = FFB_RMAX;    // constraint rows per env: 3 per ball contact + 1 per fly-fly contact + instantiated joint limits (overflow is flagged)
+constexpr int KCOL = FFB_KCOL;    // solve columns per block of M = constraint rows one block can carry (a leg at saturated actions: 5 ball contacts + limits)
 constexpr int NCH = 14;     // fly dofs a contact row can touch (deepest chain)
 constexpr int NU = 59;      // actuators
 constexpr int NWRAP = 7;    // transmission terms per actuator
@@ -53,7 +58,8 @@ constexpr int NPG = 48;     // sphere / capsule collision geoms on fly links ("p
 constexpr int NG = 72;      // all collision geoms of the fly (70), padded
 constexpr int NCP = 1152;   // candidate pairs with an ellipsoid or cylinder on one side (static list, flybody_amd/model/reach.py), padded to 64
 constexpr int NXB = 12;     // ellipsoid / cylinder geoms that can reach the ball
-constexpr int CL1 = 256;    // pairs that may pass the bounding-sphere test of one substep
+constexpr int CL1 = 192;    // pairs that may pass the bounding-sphere test of one substep (seen: 120)
+constexpr int CL2 = 24;     // pairs one narrow phase takes (seen: 9)
 constexpr int NSD = 12;     // convex pairs whose separating direction is remembered from substep to substep
 
 struct BallModel {

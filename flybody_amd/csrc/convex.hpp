@@ -319,9 +319,10 @@ CVX_FN Result distance(Geom a, Geom b, V3 n, bool have_n, float sgap, float cull
 // piece's curvature; f' being monotone, the walk crosses each breakpoint at most once.
 // Exact while the axis segment stays outside geom2 (phi > 0 at the minimiser: penetration shallower than the capsule's radius);
 // deeper, it returns the largest depth of an axis point, a lower bound of the true penetration (`shallow` = false).
-struct PResult { float dist; V3 n, pos; bool shallow; };
+struct PResult { float dist; V3 n, pos; bool shallow; float t; };
+// (`t0`, when `have_t`: the minimiser of the last substep - Newton then starts next to the answer)
 template <int N_ITER>
-CVX_FN PResult prim_convex(Geom p, Geom g) {
+CVX_FN PResult prim_convex(Geom p, Geom g, float t0 = 0.f, bool have_t = false) {
   const V3 origin = g.c;
   p.c = p.c - g.c;
   g.c = {0.f, 0.f, 0.f};
@@ -340,7 +341,7 @@ CVX_FN PResult prim_convex(Geom p, Geom g) {
   const float nudge = 2e-6f * (half + r);
   float lo = -half, hi = half;
   bool lo_ev = false, hi_ev = false, conv = half == 0.f;
-  float t = fminf(fmaxf(-dot(a, p.c), lo), hi);
+  float t = fminf(fmaxf(have_t ? t0 : -dot(a, p.c), lo), hi);
   V3 grad = {1.f, 0.f, 0.f};
   Sym3 H;
   float f = 0.f;
@@ -385,6 +386,7 @@ CVX_FN PResult prim_convex(Geom p, Geom g) {
   out.n = V3{-grad.x, -grad.y, -grad.z};
   out.pos = origin + x - (0.5f * (r + f)) * grad;
   out.shallow = f > 0.f;
+  out.t = t;
   return out;
 }
 
@@ -684,7 +686,7 @@ CVX_FN Result ell_cyl(const Geom &e, const Geom &cy, V3 n0 = V3{0.f, 0.f, 0.f}, 
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // What the kernels call.  geom1 has the lower type code (mj_collision's order), so the normal points from geom1 to geom2.
-struct Contact { float dist; V3 n, pos; };
+struct Contact { float dist; V3 n, pos; float t; };  // (t: the capsule's axis parameter of a capsule / sphere - convex pair, kept as the next substep's start)
 
 // Overlap of the two geoms along the unit direction u (from geom1 to geom2): -o(u) is a rigorous lower bound of the pair's
 // distance for every u.
@@ -733,6 +735,7 @@ CVX_FN Contact capsule_capsule(const Geom &a, const Geom &b) {
   const V3 q1 = a.c + x1 * a1, q2 = b.c + x2 * a2, d12 = q2 - q1;
   const float cd = fsqrt(dot(d12, d12));
   Contact out;
+  out.t = 0.f;
   out.n = cd >= 1e-15f ? frcp(cd) * d12 : V3{1.f, 0.f, 0.f};
   out.dist = cd - a.s0 - b.s0;
   out.pos = q1 + (a.s0 + 0.5f * out.dist) * out.n;
@@ -740,12 +743,13 @@ CVX_FN Contact capsule_capsule(const Geom &a, const Geom &b) {
 }
 
 // (`n0`: the pair's direction of the last substep, when `have_n`: the ellipsoid classes then refine it instead of searching)
-CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}, bool have_n = false) {
+CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}, bool have_n = false, float t0 = 0.f) {
   Contact out;
+  out.t = 0.f;
   if (g2.type <= CAPSULE) return capsule_capsule(g1, g2);
   if (g1.type <= CAPSULE) {  // sphere / capsule against ellipsoid / cylinder
-    const PResult r = prim_convex<8>(g1, g2);
-    out.dist = r.dist; out.n = r.n; out.pos = r.pos;
+    const PResult r = prim_convex<8>(g1, g2, t0, have_n);
+    out.dist = r.dist; out.n = r.n; out.pos = r.pos; out.t = r.t;
   } else if (g2.type == ELLIPSOID) {
     const Result r = ell_ell<8>(g1, g2, n0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;

@@ -58,7 +58,7 @@ struct alignas(64) EnvState {
   // contacts of the carried-over position stage (lane k = contact k) and the convex pairs' separating directions (flight_collide)
   float ct_f[kMC][9];
   int ct_i[kMC][3];
-  float sd_n[kNSD][3];
+  float sd_n[kNSD][4];  // direction | the capsule's axis parameter of a capsule - convex pair
   int sd_pid[kNSD];
   int nct, sd_cnt, ct_pad[2];
 };
@@ -340,7 +340,7 @@ struct Ctx {
   float ct_nx, ct_ny, ct_nz, ct_px, ct_py, ct_pz, ct_dist, ct_incl, ct_invw;
   int ct_l1, ct_l2, ct_pid, nct, ct_ovf;
   // separating-direction cache of the convex pairs: lane k < sd_cnt holds an entry
-  float sd_nx, sd_ny, sd_nz;
+  float sd_nx, sd_ny, sd_nz, sd_t;
   int sd_pid, sd_cnt;
 #ifdef FFE_STAMPS
   unsigned long long st_t0, st_acc[20];
@@ -428,7 +428,8 @@ enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 
 // of the position stage: `flight_collide` runs after stage 1 on the link frames it leaves (T.xpos / T.xmat + the link quaternions),
 // with the factor's workspace (T.LD) and the link scratch arrays (T.la .. T.lc) - both idle between stage 1 and stage 2 - as scratch.
 struct CollA { float4 gc[kMaxGeom], gq[kMaxGeom]; float lq[kMaxLink][4]; };                                        // over T.LD
-struct CollB { unsigned short cl1[128], cl2[32]; float rec[kMC][12]; float sdc[kNSD][4]; float sdn[kNSD][4]; float cl2n[32][4]; };  // over T.la .. T.lc
+constexpr int kCL2 = 24;  // pairs one narrow phase takes (typical: the touching ones, 2 - 6)
+struct CollB { unsigned short cl1[128], cl2[kCL2]; float rec[kMC][12]; float sdc[kNSD][5]; float sdn[kNSD][5]; float cl2n[kCL2][5]; };  // over T.la .. T.lc
 static_assert(sizeof(CollA) <= sizeof(Tile::LD), "collision scratch A");
 static_assert(sizeof(CollB) <= sizeof(Tile::lT) + sizeof(Tile::lb) + sizeof(Tile::lc) && offsetof(Tile, lc) == offsetof(Tile, lT) + sizeof(Tile::lT) + sizeof(Tile::lb), "collision scratch B");
 __device__ __forceinline__ CollA &coll_a(Tile &T) { return *reinterpret_cast<CollA *>(&T.LD[0]); }
@@ -491,6 +492,7 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
     bool pass = false, keep = false, have_kn = false;
     unsigned w = 0u;
     dm::V3 kn = {0.f, 0.f, 0.f};
+    float kt = 0.f;
     if (base + lane < n1) {
       w = B.cl1[base + lane];
       const int a = w & 255, b = w >> 8;
@@ -501,6 +503,7 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
         for (int k = 0; k < ncache; k++) {
           if (__float_as_int(B.sdc[k][3]) == (int)w) {
             kn = dm::V3{B.sdc[k][0], B.sdc[k][1], B.sdc[k][2]};
+            kt = B.sdc[k][4];
             keep = -cvx::overlap(ga, gb, kn) > incl;
             have_kn = true;
           }
@@ -510,12 +513,12 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
     }
     const unsigned long long bal = __ballot(pass), balk = __ballot(keep);
     const int idx = n2 + __popcll(bal & ((1ull << lane) - 1ull)), idk = nk + __popcll(balk & ((1ull << lane) - 1ull));
-    if (pass && idx < 32) { B.cl2[idx] = (unsigned short)w; float *o = B.cl2n[idx]; o[0] = kn.x; o[1] = kn.y; o[2] = kn.z; o[3] = have_kn ? 1.f : 0.f; }
-    if (keep && idk < kNSD) { B.sdn[idk][0] = kn.x; B.sdn[idk][1] = kn.y; B.sdn[idk][2] = kn.z; B.sdn[idk][3] = __int_as_float((int)w); }
+    if (pass && idx < kCL2) { B.cl2[idx] = (unsigned short)w; float *o = B.cl2n[idx]; o[0] = kn.x; o[1] = kn.y; o[2] = kn.z; o[3] = have_kn ? 1.f : 0.f; o[4] = kt; }
+    if (keep && idk < kNSD) { B.sdn[idk][0] = kn.x; B.sdn[idk][1] = kn.y; B.sdn[idk][2] = kn.z; B.sdn[idk][3] = __int_as_float((int)w); B.sdn[idk][4] = kt; }
     n2 += __popcll(bal);
     nk = min(nk + __popcll(balk), kNSD);
   }
-  if (n2 > 32) { n2 = 32; ovf = 1; }
+  if (n2 > kCL2) { n2 = kCL2; ovf = 1; }
   SYNC();
   bool hit = false;
   float dist = 0.f, margin = 0.f;
@@ -527,10 +530,10 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
     a = w & 255; b = w >> 8;
     margin = pair_margin(a, b);
     const float *kn = B.cl2n[lane];
-    const cvx::Contact ct = cvx::collide(load_geom(A, M, a), load_geom(A, M, b), dm::V3{kn[0], kn[1], kn[2]}, kn[3] != 0.f);
+    const cvx::Contact ct = cvx::collide(load_geom(A, M, a), load_geom(A, M, b), dm::V3{kn[0], kn[1], kn[2]}, kn[3] != 0.f, kn[4]);
     dist = ct.dist; nrm = ct.n; cpos = ct.pos;
     hit = dist < margin - (margin != 0.f ? M.c_gap : 0.f);  // (mj: dist <= margin is detected, dist < margin - gap is active; an inactive one takes part in nothing here)
-    if (nk + lane < kNSD) { float *o = B.sdn[nk + lane]; o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = __int_as_float((int)w); }
+    if (nk + lane < kNSD) { float *o = B.sdn[nk + lane]; o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = __int_as_float((int)w); o[4] = ct.t; }
   }
   nk = min(nk + n2, kNSD);
   unsigned long long bal = __ballot(hit);
@@ -563,13 +566,13 @@ __device__ __forceinline__ void flight_collide(Ctx &c) {
   c.nct = 0;
   if (M.ncg == 0 || (c.flags & FFE_NO_CONTACT)) return;
   CollB &B = coll_b(T);
-  if (c.lane < kNSD) { float *o = B.sdc[c.lane]; o[0] = c.sd_nx; o[1] = c.sd_ny; o[2] = c.sd_nz; o[3] = __int_as_float(c.sd_pid); }
+  if (c.lane < kNSD) { float *o = B.sdc[c.lane]; o[0] = c.sd_nx; o[1] = c.sd_ny; o[2] = c.sd_nz; o[3] = __int_as_float(c.sd_pid); o[4] = c.sd_t; }
   SYNC();
   const int r = __builtin_amdgcn_readfirstlane(flight_collide_impl(&T, c.Mp, c.lane, c.sd_cnt));
   c.nct = r & 0xff;
   c.ct_ovf |= (r >> 8) & 0xff;
   c.sd_cnt = r >> 16;
-  if (c.lane < kNSD) { const float *o = B.sdn[c.lane]; c.sd_nx = o[0]; c.sd_ny = o[1]; c.sd_nz = o[2]; c.sd_pid = __float_as_int(o[3]); }
+  if (c.lane < kNSD) { const float *o = B.sdn[c.lane]; c.sd_nx = o[0]; c.sd_ny = o[1]; c.sd_nz = o[2]; c.sd_pid = __float_as_int(o[3]); c.sd_t = o[4]; }
   if (c.lane < kMC) {
     const float *o = B.rec[c.lane];
     c.ct_nx = o[0]; c.ct_ny = o[1]; c.ct_nz = o[2]; c.ct_px = o[3]; c.ct_py = o[4]; c.ct_pz = o[5]; c.ct_dist = o[6]; c.ct_incl = o[7]; c.ct_invw = o[8];
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   for (int k = 0; k < 20; k++) c.st_acc[k] = 0;
 #endif
   load_lane_consts(c);
-  if (lane < kNSD) { c.sd_nx = S.sd_n[lane][0]; c.sd_ny = S.sd_n[lane][1]; c.sd_nz = S.sd_n[lane][2]; c.sd_pid = S.sd_pid[lane]; }
+  if (lane < kNSD) { c.sd_nx = S.sd_n[lane][0]; c.sd_ny = S.sd_n[lane][1]; c.sd_nz = S.sd_n[lane][2]; c.sd_t = S.sd_n[lane][3]; c.sd_pid = S.sd_pid[lane]; }
   c.sd_cnt = S.s1_valid ? S.sd_cnt : 0;
   float *obs = obs_out + (size_t)env * K.obs_dim;
   const bool phys_only = (mode == 2);
@@ -1716,7 +1719,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     o[0] = c.ct_nx; o[1] = c.ct_ny; o[2] = c.ct_nz; o[3] = c.ct_px; o[4] = c.ct_py; o[5] = c.ct_pz; o[6] = c.ct_dist; o[7] = c.ct_incl; o[8] = c.ct_invw;
     S.ct_i[lane][0] = c.ct_l1; S.ct_i[lane][1] = c.ct_l2; S.ct_i[lane][2] = c.ct_pid;
   }
-  if (lane < kNSD) { S.sd_n[lane][0] = c.sd_nx; S.sd_n[lane][1] = c.sd_ny; S.sd_n[lane][2] = c.sd_nz; S.sd_pid[lane] = c.sd_pid; }
+  if (lane < kNSD) { S.sd_n[lane][0] = c.sd_nx; S.sd_n[lane][1] = c.sd_ny; S.sd_n[lane][2] = c.sd_nz; S.sd_n[lane][3] = c.sd_t; S.sd_pid[lane] = c.sd_pid; }
   if (lane == 0) { S.nct = c.nct; S.sd_cnt = c.sd_cnt; S.ct_pad[0] = c.ct_ovf; S.ct_pad[1] = T.park_i[5]; }
 #ifdef FFE_STAMPS
   STAMP(10);

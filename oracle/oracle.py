@@ -143,6 +143,8 @@ def lib():
         L.fo_walk_env_step.argtypes = [vp, dp, dp, dp, dp, ip]
         L.fo_walk_env_features.argtypes = [vp, dp, dp, dp, dp]
         L.fo_walk_env_reward_factors.argtypes = [vp, C.c_int, dp]
+        L.fo_ncon_matter.restype = C.c_int
+        L.fo_ncon_matter.argtypes = [vp, vp]
         L.fo_data_contact_hist.restype = C.c_int
         L.fo_data_contact_hist.argtypes = [vp, ip, dp, C.c_int]
         L.fo_data_deep_ratio.restype = C.c_double
@@ -241,6 +243,11 @@ class OracleData:
         H = np.zeros((self.m.nv, self.m.nv)) if hessian else None
         cost = self.L.fo_debug_constraint_eval(self.m.ptr, self.ptr, _dp(jar), _dp(force), _dp(H) if hessian else None)
         return cost, force, H
+
+    @property
+    def ncon_matter(self):
+        """Detected contacts that take part in something: active, or on a body with an adhesion actuator (what the kernels keep)."""
+        return int(self.L.fo_ncon_matter(self.m.ptr, self.ptr))
 
     def contact_hist(self, reset=True):
         """(active contacts each substep used, closest approach of any candidate pair to a switching distance) since the last reset."""

@@ -55,7 +55,7 @@ def _oracle_advance(m, state, ctrl, nsteps, flags=0):
     info = []
     for _ in range(nsteps):
         d.step2()
-        info.append((d.ncon, d.nefc, m.L.fo_solver_iter(d.ptr)))
+        info.append((d.ncon_matter, d.nefc, m.L.fo_solver_iter(d.ptr)))
         d.step1()
     m.set_flags(0)
     return d.qpos.copy(), d.qvel.copy(), d.act.copy(), info
@@ -623,7 +623,7 @@ def test_abdomen_on_the_ball_one_substep(torch_mod):
         d.step1()
         d.step2()
         d.step1()
-        ncon.append(d.ncon)  # contacts of the position stage after the substep: what the kernel reports after its launch
+        ncon.append(d.ncon_matter)  # contacts of the position stage after the substep (those that take part in something): what the kernel reports after its launch
         on_ball.append(sum(1 for r in d.contacts() if names[int(r[0])] == "ball_geom" and "abdomen" in names[int(r[1])]))
         ref.append((d.qpos.copy(), d.qvel.copy(), d.act.copy()))
     q, v, a, ints = _gpu_advance(torch_mod, [s_[:3] for s_ in states], ctrls, 1)
@@ -678,8 +678,9 @@ def test_fly_fly_contact_counts_and_sensors(torch_mod):
             assert ogap.min() < 2e-6
             continue
         n_ok += 1
-        c = d.contacts()
-        assert len(c) == ints[i, 5] and sum(1 for row in c if "ball" not in names[int(row[0])] and "ball" not in names[int(row[1])]) == ints[i, 3]
+        # (the kernel keeps the contacts that take part in something: active, or with an adhesion actuator - a claw - on either body)
+        c = [row for row in d.contacts() if int(row[3]) == 0 or "claw" in names[int(row[0])] or "claw" in names[int(row[1])]]
+        assert len(c) == d.ncon_matter == ints[i, 5] and sum(1 for row in c if "ball" not in names[int(row[0])] and "ball" not in names[int(row[1])]) == ints[i, 3]
         worst_r = max(worst_r, abs(r - rew[i]))
         for name, (lo, hi) in groups.items():
             worst[name] = max(worst[name], np.abs(obs[i, lo:hi] - o[lo:hi]).max() / max(1.0, np.abs(o[lo:hi]).max()))
