@@ -41,7 +41,7 @@ def _cpu_worker(args):
     from oracle import oracle as O
 
     tables = build_tables(base_wing_pattern())
-    rq, rv = preprocess(*flight_trajectories(8, 3006))
+    rq, rv = preprocess(*flight_trajectories())  # the GPU leg's own 64-trajectory reference set (fly_envs.flight_imitation's default)
     m = O.OracleModel(os.path.join(ROOT, "flybody_amd", "assets", "fly_flight.ffmb"))
     env = O.OracleFlightEnv(m, tables, rq, rv, seed=0, env_id=idx)
     rng = np.random.RandomState(idx)

@@ -1,5 +1,7 @@
 """GPU parity tests proper: the HIP path, called through the C ABI (flybody_amd.BatchedFlyEnv -> ctypes ->
 libflybody_env.so), against the float64 CPU oracle on identical inputs.  Run with `-m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,9 +10,11 @@ from conftest import BLOB
 pytestmark = pytest.mark.gpu
 
 # float32 tolerances (stated per BASELINE.json north_star); measured headroom is recorded in DESIGN.md
-TOL_OBS_1STEP = 2e-4      # teacher-forced, one control step, scaled by max(1, |x|)
-TOL_REWARD_1STEP = 1e-5
-TOL_REWARD_OPEN_100 = 1e-4
+# (<= 3 x the values measured on MI355X with the contact stage in: observation 1.7e-5 teacher-forced / 3.5e-5 open loop, reward 1.2e-7
+# teacher-forced / 7.6e-7 open loop; profiles/r03_gpu_tests.log)
+TOL_OBS_1STEP = 6e-5      # teacher-forced, one control step, scaled by max(1, |x|)
+TOL_REWARD_1STEP = 5e-7
+TOL_REWARD_OPEN_100 = 3e-6
 # A wing blade (an ellipsoid 0.003 cm thin) moves up to 0.02 cm per substep; driven by random actions it can be found further inside an
 # abdomen segment than it is thick.  The direction of least overlap of such a pair is then one of several nearly equal candidates, not
 # unique to float32 rounding (oracle header, convex.hpp): an env-step in which the oracle meets an overlap deeper than DEEP x the
@@ -813,3 +817,19 @@ def test_double_buffered_outputs_keep_the_previous_timestep(torch_mod, wb_tables
         with pytest.raises(ValueError):
             env.step(torch.zeros(4, 12))  # a CPU tensor is not silently copied
         env.close()
+
+
+def test_open_loop_drift_report_bound(torch_mod):
+    """open-loop drift of qpos / qvel (tools/drift_report.py: ffe_physics_step, limits + fluid + actuation on,
+    wing-beat-like controls, no resynchronisation).  Without the fly's own contacts the system is smooth: the float32 drift after 100
+    control steps (400 substeps) is bounded here (3 x the measured value); the curve to 1000 steps, and the run with contacts, are
+    in profiles/r03_drift_report.log."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import drift_report
+
+    out = drift_report.run(64, B=32, nctrl=100, checkpoints=(10, 100), quiet=True)
+    print("drift without contacts:", out)
+    assert out[100][1] < 3e-5 and out[100][3] < 3e-4   # max |dqpos| (rad / cm), max rel |dqvel|
