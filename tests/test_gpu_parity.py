@@ -832,4 +832,4 @@ def test_open_loop_drift_report_bound(torch_mod):
 
     out = drift_report.run(64, B=32, nctrl=100, checkpoints=(10, 100), quiet=True)
     print("drift without contacts:", out)
-    assert out[100][1] < 3e-5 and out[100][3] < 3e-4   # max |dqpos| (rad / cm), max rel |dqvel|
+    assert out[100][1] < 6e-6 and out[100][3] < 1.5e-6   # max |dqpos| (rad / cm), max rel |dqvel|: measured 1.8e-6 / 4.1e-7 at B = 64
