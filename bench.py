@@ -309,7 +309,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE runs; KiB units; read side doubled per the gfx950 note in MI355X_MICROARCH.md - an
         # upper bound here, since these are 4-byte-per-lane reads, not the wide streams the x2 was calibrated on)
         traffic, traffic_src = None, None
-        pj = os.path.join(ROOT, "profiles", "r02_pmc_ball_kernel.json" if ball else "r02_pmc_flight_kernel.json")
+        pj = os.path.join(ROOT, "profiles", "r03_pmc_ball_kernel.json" if ball else "r03_pmc_flight_kernel.json")
         if not os.path.exists(pj):
             pj = os.path.join(ROOT, "profiles", "r01_pmc_ball_kernel.json" if ball else "r01_pmc_final_kernel.json")
         valu_frac = None

@@ -470,8 +470,14 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
   };
   int n1 = 0, ovf = 0;
   const int ncp = M.ncp;
-  for (int base = 0; base < ncp; base += kWave) {
-    const unsigned w = M.cp_pair[base + lane];
+  unsigned pw[kMaxPair / kWave];
+#pragma unroll
+  for (int r = 0; r < kMaxPair / kWave; r++) pw[r] = M.cp_pair[r * kWave + lane];  // (issued together: one L2 round trip, not one per round)
+#pragma unroll
+  for (int r = 0; r < kMaxPair / kWave; r++) {
+    const int base = r * kWave;
+    if (base >= ncp) break;
+    const unsigned w = pw[r];
     bool pass = false;
     if (w != 0xffffu) {
       const int a = w & 255, b = w >> 8;
@@ -959,8 +965,10 @@ __device__ __forceinline__ void bfactor(Ctx &c, float add0, float add1) {
 // MODE 0: factor .x only; 1: factor .y only; 2: both factors on the same right-hand side (returned as .x / .y).
 __device__ __forceinline__ float bperm_f(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
 __device__ __forceinline__ int bperm_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+// MODE 0 / 1: one right-hand side through factor .x / .y; MODE 2: the same right-hand side through both factors; MODE 3: two
+// right-hand sides (`rhs`, `rhs_b`) through factor .x at once (the contact columns of stage 2)
 template <int MODE>
-__device__ __forceinline__ float2 bsolve(Ctx &c, float rhs) {
+__device__ __forceinline__ float2 bsolve(Ctx &c, float rhs, float rhs_b = 0.f) {
   const DevModel FFE_CONST &M = *c.Mp;  // (three uniform scalars only: no need to launder the table pointer here)
   Tile &T = c.T;
   const int lane = c.lane;
@@ -968,17 +976,18 @@ __device__ __forceinline__ float2 bsolve(Ctx &c, float rhs) {
   const bool is_dof = lane < nv, branch = is_dof && lane >= nroot;
   const int d_madr = c.la_pack & 0x3ff, dep = (c.la_pack >> 10) & 0x3f, d_ndesc = c.la_pack >> 16;
   const int my_end = lane + d_ndesc, my_md = d_madr + dep;
-  const float di0 = c.dinv[0], di1 = c.dinv[1];
+  const float di0 = c.dinv[0], di1 = MODE == 3 ? c.dinv[0] : c.dinv[1];
   constexpr bool U0 = MODE != 1, U1 = MODE != 0;
   const float2 z2 = make_float2(0.f, 0.f);
   auto ldf = [&](int e) -> float2 {  // factor entry e, only the component(s) this instantiation uses
     if (MODE == 2) return T.LD[e];
     const float *p = reinterpret_cast<const float *>(T.LD) + 2 * e;
+    if (MODE == 3) { const float v = p[0]; return make_float2(v, v); }
     return MODE == 0 ? make_float2(p[0], 0.f) : make_float2(0.f, p[1]);
   };
   if (DBG(c, DBG_SKIP_SOLVE)) return is_dof ? make_float2(rhs * di0, rhs * di1) : z2;
   STAMP(6);
-  float x0 = is_dof ? rhs : 0.f, x1 = x0;
+  float x0 = is_dof ? rhs : 0.f, x1 = MODE == 3 ? (is_dof ? rhs_b : 0.f) : x0;
   // ---- x <- L^-T x, branches: step t eliminates the t-th pivot of every branch
 #pragma unroll
   for (int w = 0; w < 4; w++) {
@@ -1156,23 +1165,52 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
     for (int it = 0; it < 8; it++) {
       const float add = (act_lo ? D_lo : 0.f) + (act_hi ? D_hi : 0.f);
       const float rhs = f + (act_lo ? D_lo * ar_lo : 0.f) - (act_hi ? D_hi * ar_hi : 0.f);
+      const unsigned am = (unsigned)__ballot(cact) & ((1u << nct) - 1u);
+      bool need_y0 = false;
       if (lim_changed) {
         if (it == 0) bfactor<true>(c, add, hB);
         else bfactor<false>(c, add, 0.f);
-        y0 = bsolve<0>(c, rhs).x;
+        need_y0 = true;
         ymask = 0u;
       }
-      a = y0;
-      const unsigned am = (unsigned)__ballot(cact) & ((1u << nct) - 1u);
-      if (am) {
+      {
+        // the solves still owed with this factor - y0 and the columns of the active contacts - two right-hand sides at a time
+        unsigned todo = am & ~ymask;
+        if (need_y0) {
+          if (todo) {
+            const int k = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            float jv = 0.f;
 #pragma unroll
-        for (int k = 0; k < kMC; k++) {
-          if (((am >> k) & 1u) && !((ymask >> k) & 1u)) {
-            const float yk = bsolve<0>(c, jk[k]).x;
-            if (is_dof) yrow(k)[lane] = yk;
+            for (int q = 0; q < kMC; q++) jv = k == q ? jk[q] : jv;
+            const float2 r2 = bsolve<3>(c, rhs, jv);
+            y0 = r2.x;
+            if (is_dof) yrow(k)[lane] = r2.y;
             ymask |= 1u << k;
+          } else y0 = bsolve<0>(c, rhs).x;
+        }
+#pragma unroll 1
+        while (todo) {
+          const int k0 = __ffs(todo) - 1;
+          todo &= todo - 1u;
+          const int k1 = todo ? __ffs(todo) - 1 : -1;
+          if (k1 >= 0) todo &= todo - 1u;
+          float j0 = 0.f, j1 = 0.f;
+#pragma unroll
+          for (int q = 0; q < kMC; q++) { j0 = k0 == q ? jk[q] : j0; j1 = k1 == q ? jk[q] : j1; }
+          if (k1 >= 0) {
+            const float2 r2 = bsolve<3>(c, j0, j1);
+            if (is_dof) { yrow(k0)[lane] = r2.x; yrow(k1)[lane] = r2.y; }
+            ymask |= (1u << k0) | (1u << k1);
+          } else {
+            const float yk = bsolve<0>(c, j0).x;
+            if (is_dof) yrow(k0)[lane] = yk;
+            ymask |= 1u << k0;
           }
         }
+      }
+      a = y0;
+      if (am) {
         SYNC();
         float srow[kMC], r = 0.f;
 #pragma unroll

@@ -1,7 +1,7 @@
 # Round-end evidence on the GPU box (run through gpurun): tests, smoke, benches, rocprofv3 kernel stats, PMC passes, stamps.
-#   gpurun --timeout 1200 -- 'bash tools/gpu_round_check.sh r02'
+#   gpurun --timeout 1200 -- 'bash tools/gpu_round_check.sh r03'
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/$TAG
 O=$R/gpurun_out/$TAG
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the walk_on_ball kernel (separate rocprofv3 runs per counter group, kernel-trace only; MI355X_MICROARCH.md).
-#   bash tools/pmc_ball.sh   -> gpurun_out/pmc_ball/pass*/..., summary gpurun_out/r02_pmc_ball_kernel.json
+#   bash tools/pmc_ball.sh   -> gpurun_out/pmc_ball/pass*/..., summary gpurun_out/r03_pmc_ball_kernel.json
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_ball
@@ -28,7 +28,7 @@ for f in glob.glob("$OUT/pass*/*counter_collection.csv"):
         v = v[2:] if len(v) > 4 else v  # drop the reset launch and the first steps
         out[k] = {"median": statistics.median(v), "min": min(v), "max": max(v), "n": len(v)}
 out["_command"] = "rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 tools/bench_ball.py --batch 4096 --steps 8 --warmup 3 (one run per group)"
-json.dump(out, open("$R/gpurun_out/r02_pmc_ball_kernel.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/r03_pmc_ball_kernel.json", "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict): print(k, v["median"])
 PY

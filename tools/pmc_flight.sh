@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the flight kernel (separate rocprofv3 runs per counter group, kernel-trace only; MI355X_MICROARCH.md).
-#   bash tools/pmc_flight.sh   -> gpurun_out/pmc_flight/pass*/..., summary gpurun_out/r02_pmc_flight_kernel.json
+#   bash tools/pmc_flight.sh   -> gpurun_out/pmc_flight/pass*/..., summary gpurun_out/r03_pmc_flight_kernel.json
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_flight
@@ -28,7 +28,7 @@ for f in glob.glob("$OUT/pass*/*counter_collection.csv"):
         v = v[2:] if len(v) > 4 else v  # drop the reset launch and the first steps
         out[k] = {"median": statistics.median(v), "min": min(v), "max": max(v), "n": len(v)}
 out["_command"] = "rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 (one run per group); per-launch values of flight_step_kernel at B=8192"
-json.dump(out, open("$R/gpurun_out/r02_pmc_flight_kernel.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/r03_pmc_flight_kernel.json", "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict): print(k, v["median"])
 PY
