@@ -742,6 +742,16 @@ CVX_FN Contact capsule_capsule(const Geom &a, const Geom &b) {
   return out;
 }
 
+// cylinder - cylinder: kept out of line (never taken on the tasks' workloads: the separating-direction test culls the abdomen's
+// stacked discs) so that its code and registers do not weigh on the pair classes that run every substep
+#ifdef CVX_HOST
+static Result cyl_cyl(const Geom &g1, const Geom &g2) {
+#else
+__device__ __attribute__((noinline, cold)) Result cyl_cyl(const Geom &g1, const Geom &g2) {
+#endif
+  return distance<6, 4>(g1, g2, V3{0.f, 0.f, 0.f}, false, 0.05f * fminf(g1.s0, g2.s0), 1e30f);
+}
+
 // (`n0`: the pair's direction of the last substep, when `have_n`: the ellipsoid classes then refine it instead of searching)
 CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}, bool have_n = false, float t0 = 0.f) {
   Contact out;
@@ -757,8 +767,7 @@ CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}
     const Result r = ell_cyl<12>(g1, g2, n0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
   } else {  // cylinder - cylinder (the abdomen's segments among themselves; they never come near each other): the general iteration
-    const float sgap = 0.05f * fminf(g1.s0, g2.s0);
-    const Result r = distance<6, 4>(g1, g2, V3{0.f, 0.f, 0.f}, false, sgap, 1e30f);
+    const Result r = cyl_cyl(g1, g2);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
   }
   return out;

@@ -1,4 +1,4 @@
-"""How often walk_on_ball envs exceed the kernel's contact / constraint-row capacities (10 contacts, 32 rows, 12 rows per block:
+"""How often walk_on_ball envs exceed the kernel's contact / constraint-row capacities (16 contacts, 48 rows, 24 columns per block:
 the extra ones are dropped and the env is flagged, DESIGN.md known gaps) as a function of the action amplitude.
     python tools/ball_overflow_stats.py [batch] [steps]"""
 import os, sys, json
@@ -29,6 +29,6 @@ for amp in (0.2, 0.5, 1.0):
         ncon_max = max(ncon_max, int(ints[:, 5].max())); ncon_sum += int(ints[:, 5].sum()); it_sum += int(ints[:, 6].sum())
         last += int((ts.step_type == 2).sum())
     print(json.dumps({"action_amplitude": amp, "envs": B, "steps": steps, "env_steps_flagged_overflow": flagged_steps,
-                      "flagged_fraction": flagged_steps / (B * steps), "env_steps_in_episodes_that_exceeded [contacts>10, rows>32, block rows>12]": by_reason, "first_overflow_rate_per_env_step": new_total / max(1, exposure), "max_contacts": ncon_max, "mean_contacts": ncon_sum / (B * steps),
+                      "flagged_fraction": flagged_steps / (B * steps), "env_steps_in_episodes_that_exceeded [contacts>16, rows>48, block columns>24]": by_reason, "first_overflow_rate_per_env_step": new_total / max(1, exposure), "max_contacts": ncon_max, "mean_contacts": ncon_sum / (B * steps),
                       "mean_newton_iters": it_sum / (B * steps), "episode_ends": last}), flush=True)
     env.close()

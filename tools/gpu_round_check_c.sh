@@ -1,0 +1,8 @@
+# Round-end evidence, part C (PMC passes of the walk_on_ball kernel, batch scaling, overflow rates at full-range actions).
+set -o pipefail
+TAG=${1:-r03}
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/$TAG
+O=$R/gpurun_out/$TAG
+cd $R && bash tools/pmc_ball.sh > $O/pmc_ball.log 2>&1; tail -2 $O/pmc_ball.log
+cd $R && bash tools/batch_scaling.sh > $O/batch_scaling.log 2>&1; tail -3 $O/batch_scaling.log
+cd $R && timeout -k 10 300 python tools/ball_overflow_stats.py 2>&1 | grep -v amdgpu > $O/ball_overflow_rates.log; tail -3 $O/ball_overflow_rates.log
