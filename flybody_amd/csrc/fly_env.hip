@@ -345,6 +345,9 @@ struct Ctx {
 #ifdef FFE_STAMPS
   unsigned long long st_t0, st_acc[20];
 #endif
+#ifdef FFE_DBGCF
+  int dbg_env;
+#endif
 };
 
 // Per-lane model constants are (re)read from the lane-major tables where they are used instead of being pinned in
@@ -378,6 +381,9 @@ __device__ __forceinline__ const DevModel FFE_CONST &model(const Ctx &c) {
 #endif
 // Diagnostic build only (-DFFE_STAMPS): per-section shader-clock shares, summed over waves (cdna guide section 7,
 // "In-kernel stamps").  The stamped build is never timed or shipped; read its SHARES, not its length.
+#ifdef FFE_DBGCF
+__device__ float g_dbgcf[64][4 + 6 * 12];  // diagnostic build: the contact rows and forces of the last constraint solve of envs 0 .. 63
+#endif
 #ifdef FFE_STAMPS
 __device__ unsigned long long g_stamps[20];
 #define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[20] = {0}
@@ -388,8 +394,18 @@ __device__ unsigned long long g_stamps[20];
     c.st_acc[k] += st_t1 - c.st_t0;                                \
     c.st_t0 = st_t1;                                               \
   } while (0)
+#define CSTAMP(k)                                                                                  \
+  do {                                                                                             \
+    __builtin_amdgcn_s_waitcnt(0);                                                                 \
+    unsigned long long cs_t1 = __builtin_amdgcn_s_memtime();                                       \
+    if (lane == 0) atomicAdd(&g_stamps[k], cs_t1 - cs_t0);                                         \
+    cs_t0 = cs_t1;                                                                                 \
+  } while (0)
+#define CSTAMP_DECL unsigned long long cs_t0 = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(k) do {} while (0)
+#define CSTAMP(k) do {} while (0)
+#define CSTAMP_DECL do {} while (0)
 #endif
 // The whole-fly CoM (wave-uniform; stage 1 -> reward) lives in a spare corner of the LDS tile, not in three VGPRs.
 __device__ __forceinline__ void set_com(Ctx &c, V3 v) { if (c.lane == 0) { c.T.sens[9] = v.x; c.T.sens[10] = v.y; c.T.sens[11] = v.z; } }
@@ -452,6 +468,7 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
   CollA &A = coll_a(T);
   CollB &B = coll_b(T);
   const int ncg = M.ncg;
+  CSTAMP_DECL;
   for (int g = lane; g < ncg; g += kWave) {
     const int l = M.cg_link[g];
     const float *lq = A.lq[l];
@@ -492,6 +509,7 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
   }
   if (n1 > 128) { n1 = 128; ovf = 1; }
   SYNC();
+  CSTAMP(17);  // geom frames + bounding spheres
   int n2 = 0, nk = 0;
 #pragma unroll 1
   for (int base = 0; base < n1; base += kWave) {
@@ -526,6 +544,7 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
   }
   if (n2 > kCL2) { n2 = kCL2; ovf = 1; }
   SYNC();
+  CSTAMP(18);  // separating-direction bounds + cache
   bool hit = false;
   float dist = 0.f, margin = 0.f;
   dm::V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
@@ -542,6 +561,7 @@ __device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CON
     if (nk + lane < kNSD) { float *o = B.sdn[nk + lane]; o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = __int_as_float((int)w); o[4] = ct.t; }
   }
   nk = min(nk + n2, kNSD);
+  CSTAMP(19);  // narrow phase
   unsigned long long bal = __ballot(hit);
   if (__popcll(bal) > kMC) {  // more contacts than the solver carries: the env is flagged and the deepest are kept
     ovf = 1;
@@ -1270,6 +1290,17 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
       lim_changed = __ballot(lch) != 0ULL;
       if (__ballot(changed) == 0ULL) break;
     }
+#ifdef FFE_DBGCF
+    if (c.dbg_env < 64) {
+      float *o = g_dbgcf[c.dbg_env];
+      if (lane == 0) { o[0] = (float)nct; o[1] = (float)(__ballot(cact) & 63ull); o[2] = (float)iters; o[3] = (float)(__popcll(__ballot(act_lo)) + __popcll(__ballot(act_hi))); }
+      else { (void)__ballot(cact); (void)__ballot(act_lo); (void)__ballot(act_hi); }
+      if (lane < kMC) {
+        float *q = o + 4 + 12 * lane;
+        q[0] = c.ct_dist; q[1] = c.ct_nx; q[2] = c.ct_ny; q[3] = c.ct_nz; q[4] = c.ct_px; q[5] = c.ct_py; q[6] = c.ct_pz; q[7] = (float)c.ct_pid; q[8] = cD; q[9] = car; q[10] = cf; q[11] = c.ct_incl;
+      }
+    }
+#endif
     if (act_lo) fc += D_lo * (ar_lo - a);
     if (act_hi) fc -= D_hi * (ar_hi + a);
 #pragma unroll
@@ -1492,6 +1523,9 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   const int lane = threadIdx.x;
   EnvState &S = states[env];
   Ctx c{Mp, T, lane, K.flags, 0.f, 0.f, {0.f, 0.f}, 0u, 0u, 0u, 0u, 0u};
+#ifdef FFE_DBGCF
+  c.dbg_env = env;
+#endif
 #ifdef FFE_STAMPS
   c.st_t0 = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < 20; k++) c.st_acc[k] = 0;
@@ -2174,6 +2208,10 @@ int ffe_debug_read_stamps(unsigned long long *out16, int reset) {
   if (reset) { unsigned long long z[20] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
+#endif
+
+#ifdef FFE_DBGCF
+int ffe_debug_read_cf(float *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbgcf), sizeof(float) * 64 * (4 + 6 * 12)) == hipSuccess ? 0 : -1; }
 #endif
 
 #ifdef FFE_TRACE

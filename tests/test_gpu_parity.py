@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL_OBS_1STEP = 6e-5      # teacher-forced, one control step, scaled by max(1, |x|)
 TOL_REWARD_1STEP = 5e-7
 TOL_REWARD_OPEN_100 = 3e-6
+TOL_OBS_OPEN_30 = 3e-4     # open loop over <= 30 control steps with the fly's own contacts on (the accelerometer through the stiff contacts: measured 1.06e-4)
 # A wing blade (an ellipsoid 0.003 cm thin) moves up to 0.02 cm per substep; driven by random actions it can be found further inside an
 # abdomen segment than it is thick.  The direction of least overlap of such a pair is then one of several nearly equal candidates, not
 # unique to float32 rounding (oracle header, convex.hpp): an env-step in which the oracle meets an overlap deeper than DEEP x the
@@ -25,6 +26,9 @@ DEEP = 0.4
 # the per-substep counts of active contacts on both sides (ffe_get_task_state int 7, bits 16-31; oracle: OracleData.contact_hist); where
 # they differ the oracle must show a pair that close to switching, the step is not compared and the HIP env is put back on the oracle's state.
 FLIP_GAP_1STEP, FLIP_GAP_OPEN = 2e-6, 1e-4
+TOL_FORCED_QVEL, TOL_FORCED_QVEL_WING = 1e-3, 2e-3    # one substep from a forced-contact state, |dqvel| / max(1, |qvel|): 3 x the measured
+# 3.3e-4 (mouth parts: bodies of 1e-6 g on a stiff contact) / 7.0e-4 (a wing blade meets the abdomen at 1e6 cm/s^2 of reference
+# acceleration: the contact force agrees to 1.6e-5, the wing weighs nothing); the leg - abdomen kinds measure 6.6e-5
 
 
 def _gpu_hist(word):
@@ -344,6 +348,112 @@ def test_config2_free_flight_dynamics_only(torch_mod, wb_tables, ref_traj):
     assert np.isfinite(gq).all() and np.isfinite(gv).all()
     assert worst_q < 2e-5 and worst_v < 2e-5
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------- forced contacts
+def _forced_contact_states(wb_tables):
+    """States sorted by what touches.  From float64 oracle rollouts under full-range actions: (ii) a hind femur / tibia on an abdomen
+    cylinder, (iii) a wing blade on the abdomen or thorax (not deep, see DEEP), (iv) the mouth parts alone (labrum pair, haustellum on
+    the head).  Crafted: (i) the abdomen bent onto a retracted hind leg, 3 - 5 contacts at once up to the tibia on `abdomen_6`.
+    (VERDICT r2 item 1-iii asked for `abdomen_7` on a tarsus: with the abdomen's cylinders colliding it no longer occurs in 120 000 rollout
+    steps - profiles/r03_self_collision_flight_120k.json - and no static abdomen pose out of 20 000 reaches it with fewer than 7 contacts,
+    the kernel's capacity being 6; the chain of contacts that holds the tip off the tarsus is what (i) tests.)  Up to 12 states per kind."""
+    import json
+
+    from flybody_amd.model.blob import read_blob
+    from flybody_amd.tasks.synthetic import flight_trajectories
+    from flybody_amd.tasks.trajectories import preprocess
+    from oracle import oracle as O
+
+    names = json.load(open(BLOB.replace(".ffmb", ".json")))["geom_name"]
+    ref = preprocess(*flight_trajectories(8, 3006))
+    om = O.OracleModel(BLOB)
+    rng = np.random.RandomState(21)
+    lo = np.array([-0.2, -3, -0.5, -1, -1, -1, -1, -1, -1, -0.7, -1.05, -1.0]); hi = np.array([0.2, 3, 0.3, 1, 1, 1, 1, 1, 1, 0.7, 0.7, 1.0])
+    kinds = {"abdomen on a hind leg (crafted)": [], "hind leg on abdomen": [], "wing blade": [], "mouth parts only": []}
+    d = O.OracleData(om)
+    q0 = read_blob(BLOB)["qpos0"].copy()
+    th = np.deg2rad(47.5)
+    q0[:3], q0[3:7] = [0.0, 0.0, 1.0], [np.cos(th / 2), 0, -np.sin(th / 2), 0]
+    jn = json.load(open(BLOB.replace(".ffmb", ".json")))["jnt_name"]
+    adr = read_blob(BLOB)["jnt_qposadr"]
+    gsize = np.asarray(read_blob(BLOB)["geom_size"]).reshape(-1, 3)
+    ext = [int(adr[i]) for i, n in enumerate(jn) if n == "abdomen" or (n.startswith("abdomen_") and "abduct" not in n)]
+    abd = [int(adr[i]) for i, n in enumerate(jn) if n.startswith("abdomen_abduct")]
+    while len(kinds["abdomen on a hind leg (crafted)"]) < 12:
+        q = q0.copy()
+        q[ext], q[abd] = rng.uniform(-0.15, 0.1, len(ext)), rng.uniform(-0.1, 0.1, len(abd))
+        d.qpos[:], d.qvel[:], d.ctrl[:] = q, 0.0, 0.0
+        d.qvel[6:] = rng.randn(om.nv - 6)
+        d.step1()
+        cc = d.contacts()
+        act = [(names[int(c[0])], names[int(c[1])]) for c in cc if int(c[3]) == 0]
+        # (a leg capsule pushed into the abdomen deeper than its own radius is outside what the float32 narrow phase states as exact,
+        #  convex.hpp `prim_convex`; the contact forces keep a moving fly far from that: 1e-3 cm in the rollouts)
+        shallow = all(-c[5] < 0.8 * gsize[int(c[0])][0] for c in cc if int(c[3]) == 0)
+        if shallow and 3 <= len(act) and len(cc) <= 6 and any("tibia" in x and ("abdomen_5" in y or "abdomen_6" in y) for x, y in act):
+            kinds["abdomen on a hind leg (crafted)"].append((d.qpos.copy(), d.qvel.copy(), d.ctrl.copy()))
+    rng = np.random.RandomState(22)
+    for e in range(16):
+        oenv = O.OracleFlightEnv(om, wb_tables, *ref, seed=3, env_id=e)
+        oenv.reset()
+        d = oenv.data
+        for k in range(300):
+            oenv.step(lo + (hi - lo) * rng.uniform(0, 1, 12))
+            deep = d.deep_ratio()
+            cc = d.contacts()
+            act = [(names[int(c[0])], names[int(c[1])]) for c in cc if int(c[3]) == 0]
+            if not act or deep > 0.2 or len(cc) > 6:
+                continue
+            has = lambda a, b: any((a in x and b in y) or (a in y and b in x) for x, y in act)
+            if any("wing" in x or "wing" in y for x, y in act):
+                kind = "wing blade"
+            elif has("femur", "abdomen") or has("tibia", "abdomen"):
+                kind = "hind leg on abdomen"
+            else:
+                kind = "mouth parts only"
+            if len(kinds[kind]) < 12:
+                kinds[kind].append((d.qpos.copy(), d.qvel.copy(), d.ctrl.copy()))
+    return om, ref, kinds
+
+
+def test_forced_contacts_one_substep(torch_mod, wb_tables):
+    """The fly's own contacts in flight, by kind: from each state ONE physics substep (`ffe_physics_step`) on
+    both sides - the contact sets agree in number, and the velocities after the constraint solve agree to float32 rounding."""
+    from flybody_amd.batched_env import BatchedFlyEnv
+    from oracle import oracle as O
+
+    torch = torch_mod
+    om, ref, kinds = _forced_contact_states(wb_tables)
+    print({k: len(v) for k, v in kinds.items()})
+    assert all(len(v) >= 4 for v in kinds.values()), {k: len(v) for k, v in kinds.items()}
+    dd = O.OracleData(om)
+    for kind, states in kinds.items():
+        B = len(states)
+        env = BatchedFlyEnv(wb_tables, *ref, batch_size=B, seed=3)
+        env.reset()
+        env.set_state(torch.tensor(np.stack([s[0] for s in states])), torch.tensor(np.stack([s[1] for s in states])))
+        env.physics_step(torch.tensor(np.stack([s[2] for s in states]).astype(np.float32), device="cuda"), 1)
+        q, v = [x.cpu().numpy() for x in env.get_state()]
+        ints = env.get_task_state()[0].cpu().numpy()
+        worst, nact, nflip = 0.0, 0, 0
+        for i, s in enumerate(states):
+            dd.qpos[:], dd.qvel[:], dd.ctrl[:] = s
+            dd.contact_hist()
+            dd.step1()     # mj_step: position stage at the state (its contacts feed the solve) ...
+            dd.step2()     # ... constraint solve, integrate
+            dd.step1()     # and the position stage of the new state: the contacts the kernel reports after its substep
+            ncon, qvel = dd.ncon_matter, dd.qvel.copy()
+            dd.step2()     # (only to file the second position stage's switching gap in the history)
+            counts, gap = dd.contact_hist()
+            if int(ints[i, 7] & 255) != ncon:
+                assert gap < FLIP_GAP_1STEP, (kind, i, int(ints[i, 7] & 255), ncon, gap)
+                nflip += 1
+            nact += int(counts[0])
+            worst = max(worst, np.max(np.abs(v[i] - qvel) / np.maximum(1.0, np.abs(qvel))))
+        print(f"{kind}: {B} states, {nact} active contacts, {nflip} count flips, qvel after one substep (rel.) {worst:.2e}")
+        assert nact >= B and nflip <= 1 and worst < (TOL_FORCED_QVEL_WING if kind == "wing blade" else TOL_FORCED_QVEL), (kind, worst)
+        env.close()
 
 
 # ---------------------------------------------------------------------------------------------- edge cases
@@ -753,7 +863,7 @@ def test_trajectories_of_different_lengths(torch_mod, wb_tables, ref_traj):
             ost, orr, od, oo = e.step(a[i].astype(np.float64))
             assert (ost, od) == (st[i], disc[i]), (k, i)
             if ost != 0:
-                assert _obs_err(obs[i], oo) < TOL_OBS_1STEP, (k, i)   # the reference rows are read through the right offsets
+                assert _obs_err(obs[i], oo) < TOL_OBS_OPEN_30, (k, i)   # the reference rows are read through the right offsets
             if st[i] == 2 and i not in last_step:
                 last_step[i] = (k, float(disc[i]))
     assert [last_step[i] for i in range(3)] == [(14, 1.0), (25, 1.0), (20, 1.0)]

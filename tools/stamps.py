@@ -10,7 +10,7 @@ from flybody_amd.tasks.trajectories import preprocess
 from flybody_amd.tasks.wbpg import build_tables
 
 NAMES = ["s1 kinematics+com+cinert", "s1 cdof+velocities", "s1 rne fwd+fluid", "s1 subtree sums+joint space", "factor: M entries", "factor: elimination",
-         "stage2 glue (limits, actuation)", "triangular solves", "integration+sensors+ghost+prologue", "epilogue obs/reward", "store", "prologue: action mix, wing targets, ghost, actuator base", "sensor accumulation + actuation", "limit instantiation", "constraint block tail", "prologue: launch, state load, WBPG step", "collision (position stage)", "-", "-", "-"]
+         "stage2 glue (limits, actuation)", "triangular solves", "integration+sensors+ghost+prologue", "epilogue obs/reward", "store", "prologue: action mix, wing targets, ghost, actuator base", "sensor accumulation + actuation", "limit instantiation", "constraint block tail", "prologue: launch, state load, WBPG step", "collision (position stage)", "  of it: geom frames + bounding spheres", "  of it: separating-direction bounds + cache", "  of it: narrow phase"]
 tables = build_tables(base_wing_pattern()); rq, rv = preprocess(*flight_trajectories(64, 3006))
 B = 8192
 env = BatchedFlyEnv(tables, rq, rv, batch_size=B, seed=0)
@@ -28,7 +28,7 @@ n = 20
 for _ in range(n): env.step(a)
 torch.cuda.synchronize()
 L.ffe_debug_read_stamps(buf, 1)
-tot = sum(buf[:20])
+tot = sum(buf[:17])  # (17-19 are parts of 16)
 print(f"total shader clocks per wave-step: {tot / (n * B):.0f}")
 for k, name in enumerate(NAMES):
     print(f"{name:40s} {buf[k] / (n * B):10.0f} clk/wave-step  {100.0 * buf[k] / tot:5.1f} %")
