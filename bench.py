@@ -56,6 +56,9 @@ def _cpu_worker(args):
     return steps, time.perf_counter() - t0
 
 
+BALL_AMP = 0.2  # raw action amplitude of the walk_on_ball workload (--action-amplitude; read by the forked CPU workers too)
+
+
 def _cpu_worker_ball(args):
     """walk_on_ball twin of `_cpu_worker` (raw actions U(-0.2, 0.2), BASELINE configs[0] / [2])."""
     idx, steps = args
@@ -67,7 +70,7 @@ def _cpu_worker_ball(args):
     env = O.OracleBallEnv(m)
     env.reset()
     rng = np.random.RandomState(idx)
-    acts = rng.uniform(-0.2, 0.2, (steps, 59))
+    acts = rng.uniform(-BALL_AMP, BALL_AMP, (steps, 59))
     for k in range(10):
         env.step(acts[k])
     t0 = time.perf_counter()
@@ -141,6 +144,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--action-amplitude", type=float, default=0.2,
+                    help="walk_on_ball: raw actions U(-a, a)^59; 0.2 = BASELINE configs[2] (task_utils.py:13-24), 1.0 = every actuator saturating")
     ap.add_argument("--rehearse-gather", action="store_true",
                     help="N=1 only: also time the steps with the packing half of the per-step gather (TimestepGather without the "
                          "collective) to show what the N>1 path adds per step on the env's own GPU")
@@ -159,6 +164,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
         args.gpus = world
 
+    global BALL_AMP
+    BALL_AMP = float(args.action_amplitude)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(workload=args.workload)  # before any GPU initialisation (uses fork)
@@ -195,7 +202,7 @@ def main():
     lo = torch.tensor(spec.minimum, device=dev)
     hi = torch.tensor(spec.maximum, device=dev)
     if ball:  # BASELINE configs[2]: raw actions U(-0.2, 0.2)^59 (`task_utils.py:13-24`)
-        lo, hi = torch.full_like(lo, -0.2), torch.full_like(hi, 0.2)
+        lo, hi = torch.full_like(lo, -BALL_AMP), torch.full_like(hi, BALL_AMP)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     npool = 16
     # N = 1: the actions are this rank's own.  N > 1: the policy side sits on rank 0 - rank 0 draws the actions of
@@ -310,11 +317,10 @@ def main():
         # upper bound here, since these are 4-byte-per-lane reads, not the wide streams the x2 was calibrated on)
         traffic, traffic_src = None, None
         pj = os.path.join(ROOT, "profiles", "r03_pmc_ball_kernel.json" if ball else "r03_pmc_flight_kernel.json")
-        if not os.path.exists(pj):
-            pj = os.path.join(ROOT, "profiles", "r01_pmc_ball_kernel.json" if ball else "r01_pmc_final_kernel.json")
+        # (counters of an earlier round's kernel are not this kernel's: without the file, traffic is null)
         valu_frac = None
         flop = None
-        if os.path.exists(pj) and B == (BALL_ENVS_PER_GPU if ball else ENVS_PER_GPU) and not fake:
+        if os.path.exists(pj) and B == (BALL_ENVS_PER_GPU if ball else ENVS_PER_GPU) and not fake and (not ball or BALL_AMP == 0.2):
             with open(pj) as f:
                 pm = json.load(f)
             if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
@@ -335,7 +341,7 @@ def main():
             flop = {"flop_per_env_step": round(per), "achieved_tflops": round(value / world * per / 1e12, 3), "peak_fp32_tflops": 157.3,
                     "frac": round(value / world * per / 157.3e12, 5),
                     "source": "profiles/r02_oracle_flop_count.json (instrumented float64 oracle, tools/count_flops.py" +
-                              ("; smooth dynamics only - the oracle's dense constraint solver is not the kernel's algorithm)" if ball else ")")}
+                              ("; smooth dynamics only - the oracle's dense constraint solver is not the kernel's algorithm)" if ball else "; counted before the fly's own contacts existed: collision and contact rows excluded)")}
         algo = BALL_ALGO_BYTES_PER_ENV_STEP if ball else ALGO_BYTES_PER_ENV_STEP
         achieved = algo * B / (k_ms * 1e-3) / 1e9
         out = {
@@ -343,11 +349,11 @@ def main():
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("walk_on_ball (BASELINE configs[2]): 10 substeps @2e-4 s, ball contacts (elliptic cones, Newton + noslip), fly-fly sphere/capsule contacts, adhesion, "
+            "config": {"workload": ("walk_on_ball (BASELINE configs[2]): 10 substeps @2e-4 s, ball contacts (elliptic cones, Newton + noslip), the fly's own contacts (every geom pair MuJoCo collides: capsules, ellipsoids, cylinders), adhesion, "
                                     "filtered actuators, touch/force sensors, obs/reward/termination/auto-reset") if ball else
-                                   "flight_imitation (BASELINE configs[3]): 4 substeps @5e-5 s + WBPG + obs/reward/termination/auto-reset",
+                                   "flight_imitation (BASELINE configs[3]): 4 substeps @5e-5 s (joint limits, fluid forces, the fly's own contacts) + WBPG + obs/reward/termination/auto-reset",
                        "envs_per_gpu": B, "global_batch": world * B, "parallelism": f"env-sharded x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
-                       "actions": "raw U(-0.2, 0.2)^59, resident in HBM" if ball else "uniform over the raw action spec (canonical U(-1,1)), resident in HBM"},
+                       "actions": f"raw U(-{BALL_AMP:g}, {BALL_AMP:g})^59, resident in HBM" if ball else "uniform over the raw action spec (canonical U(-1,1)), resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ball_step_kernel" if ball else "flight_step_kernel", "kernel_ms": round(k_ms, 4), "timed_region_ms_per_launch_incl_order_kernel": round(k_ms_region, 4),
@@ -355,6 +361,13 @@ def main():
                          "note": "fused wave-per-env step keeps state on chip; VALU/LDS-latency bound, not HBM bound (DESIGN.md)"},
             "physics_substeps_per_s": round(value * env.spec.nsub, 1),
         }
+        if hasattr(env, "get_task_state") and not fake:
+            # envs that met more simultaneous contacts / constraint rows than the kernel carries (the deepest are kept):
+            # walk_on_ball: the flag is sticky over the episode; flight: a position stage of the last control step
+            ints = env.get_task_state()[0]
+            flagged = int((ints[:, 7] != 0).sum()) if ball else int((((ints[:, 7] >> 8) & 255) != 0).sum())
+            out["capacity"] = {"envs_flagged_at_end": flagged, "of": B,
+                               "limits": "16 contacts / 48 constraint rows / 24 columns per block of M" if ball else "6 simultaneous contacts of the fly with itself"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if rehearsal is not None:

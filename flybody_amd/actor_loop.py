@@ -168,7 +168,7 @@ class BatchedActorLoop:
             n = int(self._tot[0].item())
             return {"episodes": n, "episode_return": float(self._sum_ret.item()) / n if n else float("nan"),
                     "episode_length": float(self._tot[1].item()) / n if n else float("nan"),
-                    "steps_per_second": num_steps * self.env.batch_size / wall}
+                    "steps_per_second": num_steps * self.env.batch_size / wall, "capacity_flagged_envs": self._flagged()}
         start = time.perf_counter()
         for _ in range(num_steps):
             self._iteration()
@@ -177,4 +177,13 @@ class BatchedActorLoop:
         n = int(self._tot[0].item())
         return {"episodes": n, "episode_return": float(self._sum_ret.item()) / n if n else float("nan"),
                 "episode_length": float(self._tot[1].item()) / n if n else float("nan"),
-                "steps_per_second": num_steps * self.env.batch_size / wall}
+                "steps_per_second": num_steps * self.env.batch_size / wall, "capacity_flagged_envs": self._flagged()}
+
+    def _flagged(self) -> int:
+        """Envs whose step met more simultaneous contacts / constraint rows than the kernel carries (`ffe_get_task_state` int 7: the
+        deepest contacts are kept, the env is flagged - walk_on_ball: sticky over the episode; flight: the last control step)."""
+        if not hasattr(self.env, "get_task_state"):
+            return 0
+        w = self.env.get_task_state()[0][:, 7]
+        is_flight = hasattr(self.env, "ghost_accel_z")
+        return int((((w >> 8) & 255) != 0).sum()) if is_flight else int((w != 0).sum())

@@ -500,7 +500,10 @@ __device__ __forceinline__ cvx::Geom load_geom(const BTile &T, const BallModel F
 // the sphere's centre against the ellipsoid's signed distance): condim-3 ball contacts like the leg capsules', appended to the
 // `nc0` ball contacts stage 1 has just stored.  Also makes the geom frames for `convex_collide`.  Returns the number appended
 // | overflow << 8.
-__device__ __noinline__ int ball_convex(BTile *Tp, ModelPtr Mp, const int lane, const int nc0) {
+#ifndef FFB_BALLCVX_ATTR
+#define FFB_BALLCVX_ATTR __noinline__
+#endif
+__device__ FFB_BALLCVX_ATTR int ball_convex(BTile *Tp, ModelPtr Mp, const int lane, const int nc0) {
   BTile &T = *Tp;
   const BallModel FFE_GLOBAL &M = *Mp;
   const int ncg = M.ncg;
@@ -566,7 +569,10 @@ __device__ __noinline__ int ball_convex(BTile *Tp, ModelPtr Mp, const int lane, 
 // takes the next free slot after the `nprev` contacts already stored, in the same layout as self_collide's; a geom of the thorax
 // (fixed to the world) has no link: the moving geom's link is stored first and the normal turned, so that it still points from the
 // first link's geom to the second's.  Returns the number of contacts stored | overflow << 8.
-__device__ __noinline__ int convex_collide(BTile *Tp, ModelPtr Mp, const int lane, const int nprev) {
+#ifndef FFB_CONVEX_ATTR
+#define FFB_CONVEX_ATTR __noinline__
+#endif
+__device__ FFB_CONVEX_ATTR int convex_collide(BTile *Tp, ModelPtr Mp, const int lane, const int nprev) {
   BTile &T = *Tp;
   const BallModel FFE_GLOBAL &M = *Mp;
   const unsigned long long mm0 = M.cg_mmask[0], mm1 = M.cg_mmask[1];
@@ -674,7 +680,18 @@ __device__ __noinline__ int convex_collide(BTile *Tp, ModelPtr Mp, const int lan
   DM_SYNC();
   if (lane < nk) { T.sd_pid[lane] = T.tc_pid[lane]; T.sd_n[lane][0] = T.tc_n[lane][0]; T.sd_n[lane][1] = T.tc_n[lane][1]; T.sd_n[lane][2] = T.tc_n[lane][2]; T.sd_n[lane][3] = T.tc_n[lane][3]; }
   if (lane == 0) T.sd_cnt = nk;
-  const unsigned long long bal = __ballot(hit);
+  unsigned long long bal = __ballot(hit);
+  if (nprev + __popcll(bal) > NC) {  // more than the free slots: the env is flagged and the deepest are kept (as for the ball contacts)
+    ovf = 1;
+    int rank = 0;
+    for (unsigned long long m = bal; m; m &= m - 1) {
+      const int j = __ffsll((long long)m) - 1;
+      const float dj = __shfl(dist, j);
+      if (dj < dist || (dj == dist && j < lane)) rank++;
+    }
+    hit = hit && rank < NC - nprev;
+    bal = __ballot(hit);
+  }
   const int n = __popcll(bal), idx = nprev + __popcll(bal & ((1ull << lane) - 1ull));
   if (hit && idx < NC) {
     int la = M.cg_link[a], lb = M.cg_link[b];
@@ -690,9 +707,8 @@ __device__ __noinline__ int convex_collide(BTile *Tp, ModelPtr Mp, const int lan
     T.c_par[idx][0] = M.sc_K; T.c_par[idx][1] = M.sc_B; T.c_par[idx][2] = M.cg_invw[a] + M.cg_invw[b]; T.c_par[idx][3] = 0.f;
     T.c_par[idx][4] = incl;
   }
-  if (nprev + n > NC) ovf = 1;
   DM_SYNC();
-  return min(n, NC - nprev) | (ovf << 8) | (__popcll(__ballot(dropped)) << 16);
+  return n | (ovf << 8) | (__popcll(__ballot(dropped)) << 16);
 }
 
 // Fly-fly contact slots keep the dofs of geom2's chain (14 bytes), and the block-local solve column of that chain (byte 14),

@@ -339,6 +339,7 @@ struct Ctx {
   // the root, distance, includemargin, sum of the two bodies' inverse weights, the two links, pair id)
   float ct_nx, ct_ny, ct_nz, ct_px, ct_py, ct_pz, ct_dist, ct_incl, ct_invw;
   int ct_l1, ct_l2, ct_pid, nct, ct_ovf;
+  int pc;  // lane k: pair id of contact k of the previous substep's solve | 0x10000 if it was resolved inactive (-1: none): first guess of the next solve
   // separating-direction cache of the convex pairs: lane k < sd_cnt holds an entry
   float sd_nx, sd_ny, sd_nz, sd_t;
   int sd_pid, sd_cnt;
@@ -462,7 +463,10 @@ __device__ __forceinline__ cvx::Geom load_geom(const CollA &A, const DevModel FF
 // convex collider restated in convex.hpp).  A contact inside its margin but outside margin - gap exerts no force and - with no
 // adhesion actuator in the flight model - takes part in nothing: dropped.  The contacts (at most kMC, the deepest) are left in
 // `rec`.  Returns count | overflow << 8 | new cache count << 16.
-__device__ __noinline__ int flight_collide_impl(Tile *Tp, const DevModel FFE_CONST *Mp, const int lane, const int ncache) {
+#ifndef FFE_COLLIDE_ATTR
+#define FFE_COLLIDE_ATTR __noinline__
+#endif
+__device__ FFE_COLLIDE_ATTR int flight_collide_impl(Tile *Tp, const DevModel FFE_CONST *Mp, const int lane, const int ncache) {
   Tile &T = *Tp;
   const DevModel FFE_CONST &M = *Mp;
   CollA &A = coll_a(T);
@@ -1175,7 +1179,15 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
     //   a = y0 + Y f,  y0 = H0^-1 rhs,  Y = H0^-1 J',  (D^-1 + J Y) f = -(J y0 - aref)      (f = the contacts' forces)
     // i.e. m more triangular solves with the resident factor and an m x m system (rows on lanes 0 .. m-1, Gauss-Jordan by readlane).
     // Y's columns live in LDS (T.crb / T.xmat[1..]: dead in stage 2) and are kept while the limit set - hence H0 - does not change.
-    bool cact = lane < nct;   // first guess: a contact inside its includemargin pushes
+    bool cact = lane < nct;   // first guess: a contact inside its includemargin pushes - unless the previous substep's solve found this pair separating
+    if (nct) {                // (a pair drifting apart inside its margin stays that way for many substeps: each of them cost a second pass)
+      const int me = c.ct_pid & 0xffff;
+#pragma unroll
+      for (int q = 0; q < kMC; q++) {
+        const int pq = rl_i(c.pc, q);
+        if ((pq & 0x1ffff) == (me | 0x10000)) cact = false;
+      }
+    }
     float cf = 0.f, y0 = 0.f;
     unsigned ymask = 0u;
     bool lim_changed = true;
@@ -1293,8 +1305,8 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
 #ifdef FFE_DBGCF
     if (c.dbg_env < 64) {
       float *o = g_dbgcf[c.dbg_env];
-      if (lane == 0) { o[0] = (float)nct; o[1] = (float)(__ballot(cact) & 63ull); o[2] = (float)iters; o[3] = (float)(__popcll(__ballot(act_lo)) + __popcll(__ballot(act_hi))); }
-      else { (void)__ballot(cact); (void)__ballot(act_lo); (void)__ballot(act_hi); }
+      const unsigned long long bc = __ballot(cact && lane < nct), bl = __ballot(act_lo), bh = __ballot(act_hi);
+      if (lane == 0) { o[0] = (float)nct; o[1] = (float)(bc & 63ull); o[2] = (float)iters; o[3] = (float)(__popcll(bl) + __popcll(bh)); }
       if (lane < kMC) {
         float *q = o + 4 + 12 * lane;
         q[0] = c.ct_dist; q[1] = c.ct_nx; q[2] = c.ct_ny; q[3] = c.ct_nz; q[4] = c.ct_px; q[5] = c.ct_py; q[6] = c.ct_pz; q[7] = (float)c.ct_pid; q[8] = cD; q[9] = car; q[10] = cf; q[11] = c.ct_incl;
@@ -1306,6 +1318,7 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
 #pragma unroll
     for (int k = 0; k < kMC; k++)
       if (k < nct) fc += jk[k] * rl_f(cact ? cf : 0.f, k);
+    c.pc = lane < nct ? ((c.ct_pid & 0xffff) | (cact ? 0 : 0x10000)) : -1;
     ae = want_euler ? bsolve<1>(c, f + fc).y : a;
   }
   STAMP(14);  // (remaining glue inside the constraint/Euler block)
@@ -1526,6 +1539,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
 #ifdef FFE_DBGCF
   c.dbg_env = env;
 #endif
+  c.pc = -1;
 #ifdef FFE_STAMPS
   c.st_t0 = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < 20; k++) c.st_acc[k] = 0;

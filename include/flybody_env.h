@@ -145,11 +145,15 @@ int ffe_force_next_episode(ffe_handle h, const int32_t *traj_idx_host, const dou
 int ffe_get_state(ffe_handle h, double *qpos_dev, double *qvel_dev, void *stream);
 int ffe_set_state(ffe_handle h, const double *qpos_dev, const double *qvel_dev, void *stream);
 /* task-side state per env: {wbpg_step, wbpg_freq_idx, step_counter, traj_idx, needs_reset, n_active_limits,
- * solver_iters, reserved} int32[B][8] and {wbpg_ctrl_freq, ghost_pos[3], ghost_quat[4]} float64[B][8].
- * walk_on_ball handles: {contact history lo, hi, step_counter, 0, needs_reset, contacts, solver_iters, overflow (sticky over
- * the episode; bit 0 more than 10 contacts, bit 1 more than 32 constraint rows, bit 2 more than 12 rows in one block of M)} - the
- * contact history holds, 4 bits per substep for the first 16 substeps of the last control step, the number of contacts
- * inside their includemargin (the ones that received constraint rows); reals are zero */
+ * solver_iters, contacts} int32[B][8] and {wbpg_ctrl_freq, ghost_pos[3], ghost_quat[4]} float64[B][8].
+ * flight handles, int 7 (the fly's own contacts, for the parity tests): bits 0-7 contacts of the current position stage; bits
+ * 8-15 non-zero when a position stage of the last control step met more contacts than the solver carries (6; the deepest are
+ * kept); bits 16-31 the contacts each of the last step's four substeps used, 4 bits each.
+ * walk_on_ball handles: {contact history lo, hi, step_counter, fly-fly contacts, needs_reset, contacts, solver_iters, overflow
+ * (sticky over the episode; bit 0 more than 16 contacts, bit 1 more than 48 constraint rows, bit 2 more than 24 columns in one
+ * block of M)} - the contact history holds, 4 bits per substep for the first 16 substeps of the last control step, the number of
+ * contacts that received constraint rows; real 0 holds, 5 bits per substep for the first 12 substeps, the number of contacts
+ * DETECTED inside their margin (adhesion is shared over those); the other reals are zero */
 int ffe_get_task_state(ffe_handle h, int32_t *ints_dev, double *reals_dev, void *stream);
 
 /* name and duration helper for bench.py's roofline: launches `iters` steps bracketed by HIP events on `stream`
