@@ -20,4 +20,5 @@ variant stamps -DFFE_STAMPS
 variant bstamps -DFFB_STAMPS
 variant ablation -DFFE_ABLATION
 variant trace -DFFE_TRACE
+variant dbgcf -DFFE_DBGCF   # contact rows + forces of the last solve of envs 0..63 (tools/dbg_forced.py, tools/dbg_flight_iters.py)
 ls -la $C/variants

@@ -8,3 +8,4 @@ timeout -k 10 800 python -m pytest tests -m gpu -q -s 2>&1 | grep -v amdgpu | cu
 timeout -k 10 200 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu | tail -3 | tee $O/smoke.log
 timeout -k 10 300 python bench.py --rehearse-gather 2>&1 | grep -v amdgpu | tail -1 | tee $O/bench_flight.log | cut -c1-200
 timeout -k 10 300 python bench.py --workload walk_on_ball 2>&1 | grep -v amdgpu | tail -1 | tee $O/bench_walk_on_ball.log | cut -c1-200
+timeout -k 10 300 python bench.py --workload walk_on_ball --action-amplitude 1.0 --no-cpu-baseline 2>&1 | grep -v amdgpu | tail -1 | tee $O/bench_walk_on_ball_amp1.log | cut -c1-200
