@@ -39,30 +39,73 @@ struct Dev {
   unsigned long long *written;            // transitions written so far (monotone)
 };
 
-// writes the transition that starts at ring entry `s` (0 = oldest of `len` entries), spanning entries s .. len-1.
-// `rew_l` / `disc_l`: lane i holds the reward / discount of the i-th oldest entry (n_step <= 64), else they are read from the ring.
-__device__ __forceinline__ void emit(const Dev &D, int env, int lane, int first, int s, int len, const float *next_obs, unsigned long long slot,
-                                     float rew_l, float disc_l, bool in_lanes) {
+// Writes the `total` transitions that start at ring entries 0 .. total - 1 (0 = oldest of `len` held entries) and all end in
+// `next_obs`: total = 1 on an ordinary step, = len on LAST (the shorter tails).  `rew_l` / `disc_l`: lane i holds the reward /
+// discount of the i-th oldest entry (n_step <= 64), else they are read from the ring.
+// acme's order of operations (left to right from each transition's own start) is kept so that the float32 result matches a scalar
+// restatement bit for bit - but the chains of the different starts are independent: lane j runs the chain of start j, all of them
+// in lock step over one pass of the entries (values broadcast from the lanes, no memory access inside the dependent chain).  A LAST
+// step used to run its up to n chains one after the other, n (n + 1) / 2 dependent steps in one wave, and the few envs that end an
+// episode in a given call set the duration of the whole launch.
+__device__ __forceinline__ void emit_all(const Dev &D, int env, int lane, int first, int total, int len, const float *next_obs, unsigned long long base,
+                                         float rew_l, float disc_l, bool in_lanes) {
   const int n = D.n_step, O = D.obs_dim, A = D.act_dim;
   const float *rr = D.r_rew + (size_t)env * n, *rd = D.r_disc + (size_t)env * n;
-  // acme's order of operations (left to right) is kept so that the float32 result matches a scalar restatement bit for bit; the
-  // chain runs wave-uniformly on values broadcast from the lanes (no memory access inside the dependent chain)
-  float ret = 0.f, td = 1.f;
-  {
+  const unsigned long long cap = (unsigned long long)D.capacity;
+  if (total <= 64) {
+    float ret = 0.f, td = 1.f;
+    {
 #pragma clang fp contract(off)
-    for (int i = s; i < len; i++) {
-      float r_, d_;
-      if (in_lanes) { r_ = __shfl(rew_l, i); d_ = __shfl(disc_l, i); }
-      else { const int e = (first + i) % n; r_ = rr[e]; d_ = rd[e]; }
-      if (i == s) { ret = r_; td = d_; }
-      else { td *= D.gamma; ret += r_ * td; td *= d_; }
+      for (int i = 0; i < len; i++) {
+        float r_, d_;
+        if (in_lanes) { r_ = __shfl(rew_l, i); d_ = __shfl(disc_l, i); }
+        else { const int e = (first + i) % n; r_ = rr[e]; d_ = rd[e]; }
+        if (lane == i) { ret = r_; td = d_; }
+        else if (lane < i) { td *= D.gamma; ret += r_ * td; td *= d_; }
+      }
     }
-    if (lane == 0) { D.t_ret[slot] = ret; D.t_disc[slot] = td; }
+    if (lane < total) { const unsigned long long slot = (base + lane) % cap; D.t_ret[slot] = ret; D.t_disc[slot] = td; }
+  } else {  // (n_step > 64: one chain after the other)
+    for (int s = 0; s < total; s++) {
+      float ret = 0.f, td = 1.f;
+      {
+#pragma clang fp contract(off)
+        for (int i = s; i < len; i++) {
+          const int e = (first + i) % n;
+          const float r_ = rr[e], d_ = rd[e];
+          if (i == s) { ret = r_; td = d_; }
+          else { td *= D.gamma; ret += r_ * td; td *= d_; }
+        }
+      }
+      if (lane == 0) { const unsigned long long slot = (base + s) % cap; D.t_ret[slot] = ret; D.t_disc[slot] = td; }
+    }
   }
-  const int e0 = (first + s) % n;
-  const float *so = D.r_obs + ((size_t)env * n + e0) * O, *sa = D.r_act + ((size_t)env * n + e0) * A;
-  for (int k = lane; k < O; k += 64) { D.t_obs[slot * O + k] = so[k]; D.t_next[slot * O + k] = next_obs[k]; }
-  for (int k = lane; k < A; k += 64) D.t_act[slot * A + k] = sa[k];
+  // the rows: for each column block, the entries of kBatch transitions are loaded back to back and then stored, so that a LAST step's
+  // up to n copies cost n / kBatch memory round trips instead of n (the pointers may alias as far as the compiler knows: written as
+  // a plain loop it keeps every load behind the previous iteration's stores)
+  constexpr int kBatch = 16;
+  const float *ro = D.r_obs + (size_t)env * n * O, *ra = D.r_act + (size_t)env * n * A;
+  for (int k = lane; k < O; k += 64) {
+    const float nxt = next_obs[k];
+    for (int s0 = 0; s0 < total; s0 += kBatch) {
+      float v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; u++) v[u] = s0 + u < total ? ro[(size_t)((first + s0 + u) % n) * O + k] : 0.f;
+#pragma unroll
+      for (int u = 0; u < kBatch; u++)
+        if (s0 + u < total) { const unsigned long long slot = (base + s0 + u) % cap; D.t_obs[slot * O + k] = v[u]; D.t_next[slot * O + k] = nxt; }
+    }
+  }
+  for (int k = lane; k < A; k += 64) {
+    for (int s0 = 0; s0 < total; s0 += kBatch) {
+      float v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; u++) v[u] = s0 + u < total ? ra[(size_t)((first + s0 + u) % n) * A + k] : 0.f;
+#pragma unroll
+      for (int u = 0; u < kBatch; u++)
+        if (s0 + u < total) D.t_act[((base + s0 + u) % cap) * A + k] = v[u];
+    }
+  }
 }
 
 // kEnvsPerBlock envs per workgroup, one wavefront each.  The slots of the replay ring are claimed with ONE atomic per workgroup
@@ -126,8 +169,8 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void nstep_observe_kernel(Dev D
   if (total > 0) {
     unsigned long long base = s_base;
     for (int w = 0; w < wave; w++) base += (unsigned long long)s_total[w];
-    for (int j = 0; j < total; j++)  // j = 0 starts at the oldest held entry (the n-step transition once the ring is full), the rest (LAST only) start later
-      emit(D, env, lane, first, j, cnt_new, o_next, (base + j) % (unsigned long long)D.capacity, rew_l, disc_l, in_lanes);
+    // transition 0 starts at the oldest held entry (the n-step transition once the ring is full), the rest (LAST only) start later
+    emit_all(D, env, lane, first, total, cnt_new, o_next, base, rew_l, disc_l, in_lanes);
   }
   for (int k = lane; k < O; k += 64) lo[k] = o_next[k];
   if (lane == 0) { D.head[env] = head_new; D.count[env] = cnt_new; }
