@@ -742,17 +742,20 @@ CVX_FN Contact capsule_capsule(const Geom &a, const Geom &b) {
   return out;
 }
 
-// cylinder - cylinder: kept out of line (never taken on the tasks' workloads: the separating-direction test culls the abdomen's
-// stacked discs) so that its code and registers do not weigh on the pair classes that run every substep
-#ifdef CVX_HOST
-static Result cyl_cyl(const Geom &g1, const Geom &g2) {
-#else
-__device__ __attribute__((noinline, cold)) Result cyl_cyl(const Geom &g1, const Geom &g2) {
-#endif
+// cylinder - cylinder (never taken on the tasks' workloads: the separating-direction test culls the abdomen's stacked discs): the
+// general iteration.  Inline like everything else here: the kernels' collision passes are out-of-line LEAF functions, which the
+// register allocator keeps inside the caller-saved registers; a call inside one of them would turn it into a non-leaf function that
+// saves and restores every callee-saved register it keeps live across that call on every entry (measured: 1.1 GB of scratch traffic
+// per launch of the flight kernel).
+CVX_FN Result cyl_cyl(const Geom &g1, const Geom &g2) {
   return distance<6, 4>(g1, g2, V3{0.f, 0.f, 0.f}, false, 0.05f * fminf(g1.s0, g2.s0), 1e30f);
 }
 
+#ifndef CVX_ELLCYL_ITERS
+#define CVX_ELLCYL_ITERS 12
+#endif
 // (`n0`: the pair's direction of the last substep, when `have_n`: the ellipsoid classes then refine it instead of searching)
+template <bool WITH_RARE = true>
 CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}, bool have_n = false, float t0 = 0.f) {
   Contact out;
   out.t = 0.f;
@@ -763,8 +766,10 @@ CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}
   } else if (g2.type == ELLIPSOID) {
     const Result r = ell_ell<8>(g1, g2, n0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
+  } else if (!WITH_RARE) {  // (two-pass callers: the rare classes are the second pass's)
+    out.dist = 1e30f; out.n = V3{1.f, 0.f, 0.f}; out.pos = g1.c;
   } else if (g1.type == ELLIPSOID) {
-    const Result r = ell_cyl<12>(g1, g2, n0, have_n);
+    const Result r = ell_cyl<CVX_ELLCYL_ITERS>(g1, g2, n0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
   } else {  // cylinder - cylinder (the abdomen's segments among themselves; they never come near each other): the general iteration
     const Result r = cyl_cyl(g1, g2);
@@ -772,5 +777,7 @@ CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}
   }
   return out;
 }
+// the pair classes `collide<false>` leaves out (ellipsoid - cylinder: a wing near the abdomen; cylinder - cylinder)
+CVX_FN bool rare_class(int type1, int type2) { return type1 >= ELLIPSOID && type2 == CYLINDER; }
 
 }  // namespace cvx

@@ -34,7 +34,8 @@
 namespace ffe {
 
 constexpr int kMC = 6;   // contacts per env the solver carries (deepest kept; more is flagged)
-constexpr int kNSD = 8;  // convex pairs whose separating direction is remembered from substep to substep
+constexpr int kNSD = 16;  // convex pairs whose separating direction is remembered from substep to substep (a wing near the abdomen brings six
+                         // ellipsoid - cylinder pairs at once, whose search from scratch is the most expensive thing a wave can do: 25 - 100 us)
 
 // ------------------------------------------------------------------------------------------------ state
 struct alignas(64) EnvState {
@@ -53,7 +54,7 @@ struct alignas(64) EnvState {
   int wb_off, wb_len, traj_row0;  // K.tab_off[wb_freq_idx], that table's length, K.traj_off[traj_idx]: kept with the state so that the
                                   // next launch can address its table / reference rows straight from the record
   unsigned long long in_lo_mask, in_hi_mask;  // limits instantiated but resolved inactive by the last substep's solve (first guess of the next)
-  unsigned char cost_hist[32];  // solver iterations of the last control step that ended in each of 32 wing-beat phase bins (launch order)
+  unsigned char cost_hist[32];  // work estimate of the last control step that ended in each of 32 wing-beat phase bins (launch order)
   float s1_cdof[kMaxDof * 6], s1_buf[kMaxDof * 6], s1_f[kLanePad], s1_misc[16];
   // contacts of the carried-over position stage (lane k = contact k) and the convex pairs' separating directions (flight_collide)
   float ct_f[kMC][9];
@@ -339,6 +340,7 @@ struct Ctx {
   // the root, distance, includemargin, sum of the two bodies' inverse weights, the two links, pair id)
   float ct_nx, ct_ny, ct_nz, ct_px, ct_py, ct_pz, ct_dist, ct_incl, ct_invw;
   int ct_l1, ct_l2, ct_pid, nct, ct_ovf;
+  int nrare, nfac;  // second-pass collision calls and factorisations of this control step (wave-uniform): the launch-order key
   int pc;  // lane k: pair id of contact k of the previous substep's solve | 0x10000 if it was resolved inactive (-1: none): first guess of the next solve
   // separating-direction cache of the convex pairs: lane k < sd_cnt holds an entry
   float sd_nx, sd_ny, sd_nz, sd_t;
@@ -348,6 +350,9 @@ struct Ctx {
 #endif
 #ifdef FFE_DBGCF
   int dbg_env;
+#endif
+#ifdef FFE_TRACE
+  unsigned tr_coll;  // second-pass collision calls, factorisations, 100 MHz ticks spent in the collision stage
 #endif
 };
 
@@ -414,20 +419,22 @@ __device__ __forceinline__ V3 get_com(const Ctx &c) { return {c.T.sens[9], c.T.s
 // Diagnostic build only (-DFFE_TRACE): start / end shader clock and hardware slot of every wave of the last launch, for the
 // occupancy timeline of tools/wave_timeline.py (dispatch ramp, wave lifetimes, tail).
 #ifdef FFE_TRACE
+#define TRACE_HI(c) (((unsigned)(c).nrare & 0xffu) | (((unsigned)(c).nfac & 0xffu) << 8) | ((min((c).tr_coll, 0xffffu)) << 16))
 __device__ unsigned long long g_trace[32768][4];
 #define TRACE_BEGIN unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(); const int tr_prev = cost[order[blockIdx.x]]
-#define TRACE_END(slot, tr_extra)                                                                                              \
+#define TRACE_END(slot, tr_extra, tr_hi)                                                                                              \
   do {                                                                                                                         \
     __builtin_amdgcn_s_waitcnt(0);                                                                                             \
     if (threadIdx.x == 0 && (slot) < 32768) {                                                                                  \
       g_trace[slot][0] = tr_t0; g_trace[slot][1] = __builtin_amdgcn_s_memrealtime();                                               \
-      g_trace[slot][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_ID */                                               \
+      g_trace[slot][2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)tr_hi << 32);  /* HW_ID | caller's extra */                                               \
       g_trace[slot][3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) | ((unsigned long long)(tr_extra) << 8); /* XCC_ID | extra */ \
     }                                                                                                                          \
   } while (0)
 #else
 #define TRACE_BEGIN do {} while (0)
-#define TRACE_END(slot, tr_extra) do {} while (0)
+#define TRACE_HI(c) 0
+#define TRACE_END(slot, tr_extra, tr_hi) do {} while (0)
 #endif
 // timing-only ablation switches (bench experiments; results are wrong when set)
 // The in-kernel ones exist only in the -DFFE_ABLATION diagnostic build (tools/ablate.py); the shipped kernel carries neither the
@@ -444,9 +451,9 @@ enum { DBG_SKIP_FACTOR = 1 << 16, DBG_SKIP_SOLVE = 1 << 17, DBG_SKIP_STAGE1 = 1 
 // pose, head, mouth parts, wings, abdomen: fruitfly.xml:323-443, excludes :733-760) still collide in flight.  mj: mj_collision is part
 // of the position stage: `flight_collide` runs after stage 1 on the link frames it leaves (T.xpos / T.xmat + the link quaternions),
 // with the factor's workspace (T.LD) and the link scratch arrays (T.la .. T.lc) - both idle between stage 1 and stage 2 - as scratch.
-struct CollA { float4 gc[kMaxGeom], gq[kMaxGeom]; float lq[kMaxLink][4]; };                                        // over T.LD
+struct CollA { float4 gc[kMaxGeom], gq[kMaxGeom]; float lq[kMaxLink][4]; float sdc[kNSD][5], sdn[kNSD][5]; };                                        // over T.LD
 constexpr int kCL2 = 24;  // pairs one narrow phase takes (typical: the touching ones, 2 - 6)
-struct CollB { unsigned short cl1[128], cl2[kCL2]; float rec[kMC][12]; float sdc[kNSD][5]; float sdn[kNSD][5]; float cl2n[kCL2][5]; };  // over T.la .. T.lc
+struct CollB { unsigned short cl1[128], cl2[kCL2]; float rec[kMC][12]; float cl2n[kCL2][5]; };  // over T.la .. T.lc
 static_assert(sizeof(CollA) <= sizeof(Tile::LD), "collision scratch A");
 static_assert(sizeof(CollB) <= sizeof(Tile::lT) + sizeof(Tile::lb) + sizeof(Tile::lc) && offsetof(Tile, lc) == offsetof(Tile, lT) + sizeof(Tile::lT) + sizeof(Tile::lb), "collision scratch B");
 __device__ __forceinline__ CollA &coll_a(Tile &T) { return *reinterpret_cast<CollA *>(&T.LD[0]); }
@@ -463,10 +470,67 @@ __device__ __forceinline__ cvx::Geom load_geom(const CollA &A, const DevModel FF
 // convex collider restated in convex.hpp).  A contact inside its margin but outside margin - gap exerts no force and - with no
 // adhesion actuator in the flight model - takes part in nothing: dropped.  The contacts (at most kMC, the deepest) are left in
 // `rec`.  Returns count | overflow << 8 | new cache count << 16.
-#ifndef FFE_COLLIDE_ATTR
-#define FFE_COLLIDE_ATTR __noinline__
-#endif
-__device__ FFE_COLLIDE_ATTR int flight_collide_impl(Tile *Tp, const DevModel FFE_CONST *Mp, const int lane, const int ncache) {
+// Narrow phase + contact selection over the `n2` pairs the broad phase left in `cl2` (one lane per pair).  WITH_RARE = false leaves out
+// the two classes that need the most registers (ellipsoid - cylinder: a wing near the abdomen; cylinder - cylinder) - see flight_collide.
+template <bool WITH_RARE>
+__device__ __forceinline__ int collide_narrow(Tile &T, const DevModel FFE_CONST &M, const int lane, int n2, int nk, int ovf) {
+  CollA &A = coll_a(T);
+  CollB &B = coll_b(T);
+  const unsigned long long mm0 = M.cg_mmask[0], mm1 = M.cg_mmask[1];
+  const float mclass = M.c_margin;
+  auto pair_margin = [&](int a, int b) {
+    const bool ma = a < 64 ? ((mm0 >> a) & 1ull) : ((mm1 >> (a - 64)) & 1ull), mb = b < 64 ? ((mm0 >> b) & 1ull) : ((mm1 >> (b - 64)) & 1ull);
+    return (ma || mb) ? mclass : 0.f;
+  };
+  bool hit = false;
+  float dist = 0.f, margin = 0.f, ctt = 0.f;
+  dm::V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
+  int a = 0, b = 0;
+  unsigned w = 0u;
+  if (lane < n2) {
+    w = B.cl2[lane];
+    a = w & 255; b = w >> 8;
+    margin = pair_margin(a, b);
+    const float *kn = B.cl2n[lane];
+    const cvx::Contact ct = cvx::collide<WITH_RARE>(load_geom(A, M, a), load_geom(A, M, b), dm::V3{kn[0], kn[1], kn[2]}, kn[3] != 0.f, kn[4]);
+    dist = ct.dist; nrm = ct.n; cpos = ct.pos; ctt = ct.t;
+    hit = dist < margin - (margin != 0.f ? M.c_gap : 0.f);  // (mj: dist <= margin is detected, dist < margin - gap is active; an inactive one takes part in nothing here)
+  }
+  {
+    // the pair's direction, for the next substep's bound and warm start; when the cache cannot take them all, the classes whose cold
+    // search costs most go first (ellipsoid - cylinder, then ellipsoid - ellipsoid, then the capsule classes' axis parameter)
+    const int ta = M.cg_type[a], tb = M.cg_type[b];
+    const int prio = lane < n2 ? (cvx::rare_class(ta, tb) ? 2 : (ta >= cvx::ELLIPSOID ? 1 : 0)) : -1;
+    const unsigned long long b2 = __ballot(prio == 2), b1 = __ballot(prio == 1), b0 = __ballot(prio == 0), below = (1ull << lane) - 1ull;
+    const int pos = nk + (prio == 2 ? __popcll(b2 & below) : prio == 1 ? __popcll(b2) + __popcll(b1 & below) : __popcll(b2) + __popcll(b1) + __popcll(b0 & below));
+    if (prio >= 0 && pos < kNSD) { float *o = A.sdn[pos]; o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = __int_as_float((int)w); o[4] = ctt; }
+  }
+  nk = min(nk + n2, kNSD);
+  unsigned long long bal = __ballot(hit);
+  if (__popcll(bal) > kMC) {  // more contacts than the solver carries: the env is flagged and the deepest are kept
+    ovf = 1;
+    int rank = 0;
+    for (unsigned long long m = bal; m; m &= m - 1) {
+      const int j = __ffsll((long long)m) - 1;
+      const float dj = __shfl(dist, j);
+      if (dj < dist || (dj == dist && j < lane)) rank++;
+    }
+    hit = hit && rank < kMC;
+    bal = __ballot(hit);
+  }
+  const int n = __popcll(bal), idx = __popcll(bal & ((1ull << lane) - 1ull));
+  if (hit) {
+    float *o = B.rec[idx];
+    o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = cpos.x; o[4] = cpos.y; o[5] = cpos.z; o[6] = dist;
+    o[7] = margin - (margin != 0.f ? M.c_gap : 0.f); o[8] = M.cg_invw[a] + M.cg_invw[b];
+    o[9] = __int_as_float(M.cg_link[a]); o[10] = __int_as_float(M.cg_link[b]); o[11] = __int_as_float((int)w);
+  }
+  SYNC();
+  return n | (ovf << 8) | (nk << 16);
+}
+
+
+__device__ __noinline__ int flight_collide_a(Tile *Tp, const DevModel FFE_CONST *Mp, const int lane, const int ncache) {
   Tile &T = *Tp;
   const DevModel FFE_CONST &M = *Mp;
   CollA &A = coll_a(T);
@@ -515,6 +579,7 @@ __device__ FFE_COLLIDE_ATTR int flight_collide_impl(Tile *Tp, const DevModel FFE
   SYNC();
   CSTAMP(17);  // geom frames + bounding spheres
   int n2 = 0, nk = 0;
+  bool any_rare = false;
 #pragma unroll 1
   for (int base = 0; base < n1; base += kWave) {
     bool pass = false, keep = false, have_kn = false;
@@ -528,65 +593,45 @@ __device__ FFE_COLLIDE_ATTR int flight_collide_impl(Tile *Tp, const DevModel FFE
       const float margin = pair_margin(a, b), incl = margin - (margin != 0.f ? M.c_gap : 0.f);  // (only a contact inside margin - gap matters here)
       pass = cvx::separation_bound(ga, gb) <= incl;
       if (pass) {
+        int alt = -1;
         for (int k = 0; k < ncache; k++) {
-          if (__float_as_int(B.sdc[k][3]) == (int)w) {
-            kn = dm::V3{B.sdc[k][0], B.sdc[k][1], B.sdc[k][2]};
-            kt = B.sdc[k][4];
-            keep = -cvx::overlap(ga, gb, kn) > incl;
+          const int pk = __float_as_int(A.sdc[k][3]);
+          if (pk == (int)w) {
+            kn = dm::V3{A.sdc[k][0], A.sdc[k][1], A.sdc[k][2]};
+            kt = A.sdc[k][4];
             have_kn = true;
-          }
+          } else if ((pk & 255) == a && M.cg_type[pk >> 8] == gb.type) alt = k;
         }
+        // A wing sweeps over the abdomen's stacked segments, a new pair every substep or two: a pair seen for the first time borrows the
+        // direction its ellipsoid holds against a neighbouring geom of the same kind.  As a bound any direction is rigorous; as a start it
+        // saves the narrow phase its search from scratch (the most expensive thing a wave does: it set the length of whole launches).
+        if (!have_kn && alt >= 0 && ga.type == cvx::ELLIPSOID) { kn = dm::V3{A.sdc[alt][0], A.sdc[alt][1], A.sdc[alt][2]}; have_kn = true; }
+        if (have_kn) keep = -cvx::overlap(ga, gb, kn) > incl;
         pass = !keep;
       }
     }
+    any_rare = any_rare || __ballot(pass && cvx::rare_class(M.cg_type[w & 255], M.cg_type[w >> 8])) != 0ull;
     const unsigned long long bal = __ballot(pass), balk = __ballot(keep);
     const int idx = n2 + __popcll(bal & ((1ull << lane) - 1ull)), idk = nk + __popcll(balk & ((1ull << lane) - 1ull));
     if (pass && idx < kCL2) { B.cl2[idx] = (unsigned short)w; float *o = B.cl2n[idx]; o[0] = kn.x; o[1] = kn.y; o[2] = kn.z; o[3] = have_kn ? 1.f : 0.f; o[4] = kt; }
-    if (keep && idk < kNSD) { B.sdn[idk][0] = kn.x; B.sdn[idk][1] = kn.y; B.sdn[idk][2] = kn.z; B.sdn[idk][3] = __int_as_float((int)w); B.sdn[idk][4] = kt; }
+    if (keep && idk < kNSD) { A.sdn[idk][0] = kn.x; A.sdn[idk][1] = kn.y; A.sdn[idk][2] = kn.z; A.sdn[idk][3] = __int_as_float((int)w); A.sdn[idk][4] = kt; }
     n2 += __popcll(bal);
     nk = min(nk + __popcll(balk), kNSD);
   }
   if (n2 > kCL2) { n2 = kCL2; ovf = 1; }
   SYNC();
   CSTAMP(18);  // separating-direction bounds + cache
-  bool hit = false;
-  float dist = 0.f, margin = 0.f;
-  dm::V3 nrm = {1.f, 0.f, 0.f}, cpos = {0.f, 0.f, 0.f};
-  int a = 0, b = 0;
-  unsigned w = 0u;
-  if (lane < n2) {
-    w = B.cl2[lane];
-    a = w & 255; b = w >> 8;
-    margin = pair_margin(a, b);
-    const float *kn = B.cl2n[lane];
-    const cvx::Contact ct = cvx::collide(load_geom(A, M, a), load_geom(A, M, b), dm::V3{kn[0], kn[1], kn[2]}, kn[3] != 0.f, kn[4]);
-    dist = ct.dist; nrm = ct.n; cpos = ct.pos;
-    hit = dist < margin - (margin != 0.f ? M.c_gap : 0.f);  // (mj: dist <= margin is detected, dist < margin - gap is active; an inactive one takes part in nothing here)
-    if (nk + lane < kNSD) { float *o = B.sdn[nk + lane]; o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = __int_as_float((int)w); o[4] = ct.t; }
-  }
-  nk = min(nk + n2, kNSD);
-  CSTAMP(19);  // narrow phase
-  unsigned long long bal = __ballot(hit);
-  if (__popcll(bal) > kMC) {  // more contacts than the solver carries: the env is flagged and the deepest are kept
-    ovf = 1;
-    int rank = 0;
-    for (unsigned long long m = bal; m; m &= m - 1) {
-      const int j = __ffsll((long long)m) - 1;
-      const float dj = __shfl(dist, j);
-      if (dj < dist || (dj == dist && j < lane)) rank++;
-    }
-    hit = hit && rank < kMC;
-    bal = __ballot(hit);
-  }
-  const int n = __popcll(bal), idx = __popcll(bal & ((1ull << lane) - 1ull));
-  if (hit) {
-    float *o = B.rec[idx];
-    o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = cpos.x; o[4] = cpos.y; o[5] = cpos.z; o[6] = dist;
-    o[7] = margin - (margin != 0.f ? M.c_gap : 0.f); o[8] = M.cg_invw[a] + M.cg_invw[b];
-    o[9] = __int_as_float(M.cg_link[a]); o[10] = __int_as_float(M.cg_link[b]); o[11] = __int_as_float((int)w);
-  }
-  SYNC();
-  return n | (ovf << 8) | (nk << 16);
+  // The narrow phase of the classes that run every substep is part of this (leaf) function: it stays within the caller-saved registers, so
+  // the call costs no save / restore traffic.  A pair of a rare class sends the whole narrow phase to the second function.
+  if (any_rare) return 0x40000000 | n2 | (nk << 8) | (ovf << 16);
+  const int r = collide_narrow<false>(T, M, lane, n2, nk, ovf);
+  CSTAMP(19);  // narrow phase (common classes)
+  return r;
+}
+
+// the same with every pair class (entered only when the broad phase left an ellipsoid - cylinder or cylinder - cylinder pair)
+__device__ __noinline__ int flight_collide_b(Tile *Tp, const DevModel FFE_CONST *Mp, const int lane, const int packed) {
+  return collide_narrow<true>(*Tp, *Mp, lane, packed & 0xff, (packed >> 8) & 0xff, (packed >> 16) & 1);
 }
 
 // the position stage's collision: cache in, contacts + cache out (lane-resident, see Ctx)
@@ -595,14 +640,25 @@ __device__ __forceinline__ void flight_collide(Ctx &c) {
   Tile &T = c.T;
   c.nct = 0;
   if (M.ncg == 0 || (c.flags & FFE_NO_CONTACT)) return;
+  CollA &A = coll_a(T);
   CollB &B = coll_b(T);
-  if (c.lane < kNSD) { float *o = B.sdc[c.lane]; o[0] = c.sd_nx; o[1] = c.sd_ny; o[2] = c.sd_nz; o[3] = __int_as_float(c.sd_pid); o[4] = c.sd_t; }
+  if (c.lane < kNSD) { float *o = A.sdc[c.lane]; o[0] = c.sd_nx; o[1] = c.sd_ny; o[2] = c.sd_nz; o[3] = __int_as_float(c.sd_pid); o[4] = c.sd_t; }
   SYNC();
-  const int r = __builtin_amdgcn_readfirstlane(flight_collide_impl(&T, c.Mp, c.lane, c.sd_cnt));
+#ifdef FFE_TRACE
+  const unsigned long long tr_c0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int r = __builtin_amdgcn_readfirstlane(flight_collide_a(&T, c.Mp, c.lane, c.sd_cnt));
+  if (r & 0x40000000) {
+    r = __builtin_amdgcn_readfirstlane(flight_collide_b(&T, c.Mp, c.lane, r));
+    c.nrare++;
+  }
+#ifdef FFE_TRACE
+  c.tr_coll += (unsigned)(__builtin_amdgcn_s_memrealtime() - tr_c0);
+#endif
   c.nct = r & 0xff;
   c.ct_ovf |= (r >> 8) & 0xff;
   c.sd_cnt = r >> 16;
-  if (c.lane < kNSD) { const float *o = B.sdn[c.lane]; c.sd_nx = o[0]; c.sd_ny = o[1]; c.sd_nz = o[2]; c.sd_pid = __float_as_int(o[3]); c.sd_t = o[4]; }
+  if (c.lane < kNSD) { const float *o = A.sdn[c.lane]; c.sd_nx = o[0]; c.sd_ny = o[1]; c.sd_nz = o[2]; c.sd_pid = __float_as_int(o[3]); c.sd_t = o[4]; }
   if (c.lane < kMC) {
     const float *o = B.rec[c.lane];
     c.ct_nx = o[0]; c.ct_ny = o[1]; c.ct_nz = o[2]; c.ct_px = o[3]; c.ct_py = o[4]; c.ct_pz = o[5]; c.ct_dist = o[6]; c.ct_incl = o[7]; c.ct_invw = o[8];
@@ -1171,6 +1227,7 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
   if (ex_any == 0ULL && nct == 0) {
     // no limit instantiated, no contact: one dual factorisation, one dual solve
     bfactor<true>(c, 0.f, hB);
+    c.nfac++;
     if (want_euler) { const float2 r = bsolve<2>(c, f); a = r.x; ae = r.y; }
     else { a = bsolve<0>(c, f).x; ae = a; }
   } else {
@@ -1202,6 +1259,7 @@ __device__ __forceinline__ V3 stage2(Ctx &c, float qfrc_act, bool integrate, boo
       if (lim_changed) {
         if (it == 0) bfactor<true>(c, add, hB);
         else bfactor<false>(c, add, 0.f);
+        c.nfac++;
         need_y0 = true;
         ymask = 0u;
       }
@@ -1540,6 +1598,10 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   c.dbg_env = env;
 #endif
   c.pc = -1;
+  c.nrare = 0; c.nfac = 0;
+#ifdef FFE_TRACE
+  c.tr_coll = 0u;
+#endif
 #ifdef FFE_STAMPS
   c.st_t0 = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < 20; k++) c.st_acc[k] = 0;
@@ -1780,20 +1842,26 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
     S.wb_off = wb_off; S.wb_len = wb_len; S.traj_row0 = traj_row0;
     S.lo_mask = lo_mask; S.hi_mask = hi_mask; S.in_lo_mask = in_lo; S.in_hi_mask = in_hi; S.solver_iters = iters;
     S.nactive = __popcll(lo_mask) + __popcll(hi_mask);
-    // Key of the next launch's order = the solver work the next step is expected to need.  Joint limits are hit at fixed
-    // phases of the wing beat (stroke reversal), so the work is periodic in the WBPG phase: besides this step's own iterations
-    // the key takes the iterations recorded, one beat earlier, in the phase bins the next step will fall into (misses of
-    // heavy steps on the bench workload: 21 % with the last step alone, 1.3 % with both; tools/cost_history.py).
-    int pred = iters;
+    // Key of the next launch's order = how long this env's wave is expected to run next step, in units of about 5 us.  A launch is two
+    // rounds of resident waves and ends with its slowest one (wave lifetimes: mean 270 us, p99 390, longest 550 - 630), so the long ones
+    // must start first.  The estimate is a least-squares fit of traced lifetimes (tools/wave_cost_fit.py): 14 us per factorisation, 2.6 us
+    // per contact and substep, 18 us per second-pass collision call (a wing meeting the abdomen's cylinders).  Joint limits are hit, and
+    // the wings pass the abdomen, at fixed phases of the wing beat, so the work is periodic in the WBPG phase: the key is the larger of this
+    // step's work and the work recorded, one beat earlier, in the phase bins the next step will fall into.  Measured against the alternatives
+    // (DESIGN.md section 6 item 9): round 2's key (solver passes only) 9.54 M env-steps/s, the wave's own measured lifetime 9.55 M (it mostly
+    // records which round the wave ran in), lifetime + phase history 10.35 M, this one 10.48 M.
+    const int hist_c = T.park_i[5], csum = (hist_c & 15) + ((hist_c >> 4) & 15) + ((hist_c >> 8) & 15) + ((hist_c >> 12) & 15);
+    const int work = min(255, (11 * c.nfac + 2 * csum + 14 * c.nrare) / 2);
+    int pred = work;
     if (!phys_only) {
       const int off = K.tab_off[wb_idx], len = K.tab_off[wb_idx + 1] - off;
       const int b = min(31, (int)(K.phase_frac[off + wb_step] * 32.0));
       const int nb = min(31, (int)(K.phase_frac[off + (wb_step + 1 < len ? wb_step + 1 : 0)] * 32.0));
       if (do_reset) { for (int k = 0; k < 32; k++) S.cost_hist[k] = 0; }
-      else S.cost_hist[b] = (unsigned char)min(iters, 255);
+      else S.cost_hist[b] = (unsigned char)work;
       pred = max(pred, max((int)S.cost_hist[nb], (int)S.cost_hist[(nb + 1) & 31]));
     }
-    cost[env] = 8 * pred + min(7, S.nactive);
+    cost[env] = pred;
   }
   // carry the final stage-1 results to the next launch (a reset's single evaluation is that of the FIRST state)
   for (int e = lane; e < kMaxDof * 6; e += kWave) { S.s1_cdof[e] = (&T.cdof[0][0])[e]; S.s1_buf[e] = (&T.buf[0][0])[e]; }
@@ -1811,7 +1879,7 @@ __global__ __launch_bounds__(kWave, FFE_WAVES_PER_SIMD) void flight_step_kernel(
   STAMP(10);
   if (lane == 0) for (int k = 0; k < 20; k++) atomicAdd(&g_stamps[k], c.st_acc[k]);
 #endif
-  TRACE_END(blockIdx.x, (unsigned)(iters & 0xff) | ((unsigned)(__popcll(lo_mask) + __popcll(hi_mask)) << 8) | ((unsigned)(tr_prev & 0xffff) << 16));  // this step's solver iterations, active limits at its end, the sort key it was launched with
+  TRACE_END(blockIdx.x, (unsigned long long)((unsigned)(iters & 0xff) | ((unsigned)(__popcll(lo_mask) + __popcll(hi_mask)) << 8) | ((unsigned)(tr_prev & 0xffff) << 16)) | ((unsigned long long)(T.park_i[5] & 0xffff) << 32), TRACE_HI(c));  // this step's solver iterations, active limits at its end, the sort key it was launched with, the contacts each substep used (4 bits each)
 }
 
 __global__ void init_states_kernel(EnvState *states, int *order, int *cost, int batch) {
