@@ -107,7 +107,6 @@ struct alignas(16) BTile {
   unsigned char c_chain[NC][16];
   float c_par[NC][5];  // K, B, invweight, friction, includemargin
   float c_pos[NC][3], c_frame[NC][9], c_dist[NC];
-  float c_J[NC][3][NCH], c_Jb[NC][3][3];
   float c_D[NC], c_mu[NC], c_aref[NC][3], c_f[NC][3], c_w[NC][3];
   // constraint rows: 3 per contact (normal, two tangents), then the instantiated joint limits
   float r_y0[RMAX], r_lam[RMAX], r_f[RMAX];
@@ -713,7 +712,26 @@ __device__ FFB_CONVEX_ATTR int convex_collide(BTile *Tp, ModelPtr Mp, const int 
 
 // Fly-fly contact slots keep the dofs of geom2's chain (14 bytes), and the block-local solve column of that chain (byte 14),
 // in the slot's unused ball Jacobian.
-__device__ __forceinline__ unsigned char *sc_chain_b(BTile &T, int k) { return reinterpret_cast<unsigned char *>(&T.c_Jb[k][0][0]); }
+__device__ __forceinline__ unsigned char *sc_chain_b(BTile &T, int k) { return reinterpret_cast<unsigned char *>(&T.c_frame[k][3]); }  // (a fly-fly slot uses row 0 of its frame only: 24 spare bytes)
+__device__ __forceinline__ const unsigned char *sc_chain_b(const BTile &T, int k) { return reinterpret_cast<const unsigned char *>(&T.c_frame[k][3]); }
+
+// The contact rows' Jacobian entries are evaluated where they are used, from the dof's motion axes (T.C) and the contact's point and
+// frame.  As a table (16 contacts x 3 rows x 14 chain dofs, plus the ball's 3 x 3 per contact) they took 3.2 KB of the tile - the
+// difference between 6 and 8 resident waves per CU, i.e. between three rounds of waves per launch and two (walk_on_ball +39 %).
+// cj_u: velocity of contact k's point per unit rate of fly dof f (about the fixed thorax origin c0).
+__device__ __forceinline__ V3 cj_u(const BTile &T, int k, int f, V3 c0) {
+  const S6 cd = ld6(T.C[f]);
+  const V3 r = V3{T.c_pos[k][0], T.c_pos[k][1], T.c_pos[k][2]} - c0;
+  return lin(cd) + cross(ang(cd), r);
+}
+__device__ __forceinline__ float cj_row(const BTile &T, int k, int r, V3 u) { const float *fr = &T.c_frame[k][3 * r]; return fr[0] * u.x + fr[1] * u.y + fr[2] * u.z; }
+// the ball's three entries of row r of ball contact k (geom1 = the ball, rates = its angular velocity in body axes; Rb = its rotation)
+__device__ __forceinline__ V3 cj_ball(const BTile &T, int k, int r, const M3 &Rb, V3 bc) {
+  const V3 rr = V3{T.c_pos[k][0], T.c_pos[k][1], T.c_pos[k][2]} - bc;
+  const float *fr = &T.c_frame[k][3 * r];
+  const V3 u0 = cross(V3{Rb.m0, Rb.m3, Rb.m6}, rr), u1 = cross(V3{Rb.m1, Rb.m4, Rb.m7}, rr), u2 = cross(V3{Rb.m2, Rb.m5, Rb.m8}, rr);
+  return V3{-(fr[0] * u0.x + fr[1] * u0.y + fr[2] * u0.z), -(fr[0] * u1.x + fr[1] * u1.y + fr[2] * u1.z), -(fr[0] * u2.x + fr[1] * u2.y + fr[2] * u2.z)};
+}
 
 // mj: mj_makeConstraint rows of the fly-fly contacts (condim 1: one frictionless row each, J = n . (jacp2 - jacp1) at the
 // contact point), mj_makeImpedance, mj_referenceConstraint; and mj_transmission mjTRN_BODY for the adhesion actuators: an
@@ -740,7 +758,6 @@ __device__ __noinline__ void self_rows(BTile *Tp, ModelPtr Mp, const int lane, c
       vv = T.V[f];
     }
     if (half < 2 && p < NCH) {
-      T.c_J[k][half][p] = jv;
       if (half == 0) T.c_chain[k][p] = (unsigned char)f; else sc_chain_b(T, k)[p] = (unsigned char)f;
     }
     const float vel = wave_sum(jv * vv);
@@ -789,8 +806,9 @@ __device__ __noinline__ void self_rows(BTile *Tp, ModelPtr Mp, const int lane, c
 
 // J' of the fly-fly rows into the right-hand sides of a block solve: over geom1's chain, then (the chains may share dofs)
 // accumulated over geom2's chain.  X4 has been zeroed and filled by the other rows; columns as assigned in stage 2.
-__device__ __noinline__ void self_rhs(BTile *Tp, const int lane, const int nc, const int nsc, const int nrc, const int cb) {
+__device__ __noinline__ void self_rhs(BTile *Tp, const int lane, const int nc, const int nsc, const int nrc, const int cb, const float c0x, const float c0y, const float c0z) {
   BTile &T = *Tp;
+  const V3 c0 = {c0x, c0y, c0z};
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     DM_SYNC();
@@ -800,14 +818,15 @@ __device__ __noinline__ void self_rhs(BTile *Tp, const int lane, const int nc, c
       const int col = (half == 0 ? (int)T.r_col[nrc + j] : (int)sc_chain_b(T, k)[14]) + 1 - cb;
       if (p < nch && col >= 0 && col < 4) {
         const int f = half == 0 ? (int)T.c_chain[k][p] : (int)sc_chain_b(T, k)[p];
-        (&T.X4[f].x)[col] += T.c_J[k][half][p];
+        (&T.X4[f].x)[col] += (half == 0 ? -1.f : 1.f) * cj_row(T, k, 0, cj_u(T, k, f, c0));
       }
     }
   }
 }
 // rows of G owned by fly-fly contacts: J over each of the two chains against the solved columns of that chain's block
-__device__ __noinline__ void self_gacc(BTile *Tp, const int lane, const int nc, const int nsc, const int nrc, const int cb) {
+__device__ __noinline__ void self_gacc(BTile *Tp, const int lane, const int nc, const int nsc, const int nrc, const int cb, const float c0x, const float c0y, const float c0z) {
   BTile &T = *Tp;
+  const V3 c0 = {c0x, c0y, c0z};
   if (lane < nrc || lane >= nrc + nsc) return;
   const int k = nc + lane - nrc, gtri = lane * (lane + 1) / 2;
 #pragma unroll 1
@@ -815,8 +834,9 @@ __device__ __noinline__ void self_gacc(BTile *Tp, const int lane, const int nc, 
     const int nch = (T.c_nch[k] >> (8 * half)) & 0xff, b = (T.c_blk[k] >> (8 * half)) & 0xff;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = 0; p < nch; p++) {
-      const float jv = T.c_J[k][half][p];
-      const float4 y = T.X4[half == 0 ? (int)T.c_chain[k][p] : (int)sc_chain_b(T, k)[p]];
+      const int f = half == 0 ? (int)T.c_chain[k][p] : (int)sc_chain_b(T, k)[p];
+      const float jv = (half == 0 ? -1.f : 1.f) * cj_row(T, k, 0, cj_u(T, k, f, c0));
+      const float4 y = T.X4[f];
       acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
     }
 #pragma unroll
@@ -833,14 +853,17 @@ __device__ __noinline__ void self_gacc(BTile *Tp, const int lane, const int nc, 
 }
 
 // sum over the fly-fly contacts whose row touches fly dof (blk, li) of J[c][p] * w[c][0]
-__device__ __forceinline__ float self_gather(const Ctx &c, unsigned sbl, const float (*w)[3]) {
+__device__ __forceinline__ float self_gather(const Ctx &c, unsigned sbl, int f, V3 c0, const float (*w)[3]) {
   const BTile &T = *c.T;
   const unsigned li = sbl >> 8, blk = sbl & 0xffu;
   float acc = 0.f;
   for (int k = c.nc; k < c.nc + c.nsc; k++) {
     const unsigned bl = (unsigned)T.c_blk[k], am = T.c_amask[k];
-    if ((bl & 0xffu) == blk && ((am >> li) & 1u)) acc += T.c_J[k][0][__popc(am & 0xffffu & ((1u << li) - 1u))] * w[k][0];
-    if ((bl >> 8) == blk && ((am >> (16 + li)) & 1u)) acc += T.c_J[k][1][__popc((am >> 16) & ((1u << li) - 1u))] * w[k][0];
+    const bool in1 = (bl & 0xffu) == blk && ((am >> li) & 1u), in2 = (bl >> 8) == blk && ((am >> (16 + li)) & 1u);
+    if (in1 || in2) {  // (dof f lies on geom1's chain: -n . u, on geom2's: +n . u, on both: they cancel)
+      const float jn = cj_row(T, k, 0, cj_u(T, k, f, c0));
+      acc += ((in2 ? jn : 0.f) - (in1 ? jn : 0.f)) * w[k][0];
+    }
   }
   return acc;
 }
@@ -1160,7 +1183,7 @@ __device__ __forceinline__ void stage1(Ctx &c) {
 }
 
 // sum over the contacts whose chain contains fly dof (blk, li) of  sum_r J[c][r][p] * w[c][r]
-__device__ __forceinline__ float contact_gather(const Ctx &c, unsigned sbl, const float (*w)[3]) {
+__device__ __forceinline__ float contact_gather(const Ctx &c, unsigned sbl, int f, V3 c0, const float (*w)[3]) {
   const BTile &T = *c.T;
   const unsigned li = sbl >> 8;
   unsigned bm = T.c_bmask[sbl & 0xffu];
@@ -1170,8 +1193,8 @@ __device__ __forceinline__ float contact_gather(const Ctx &c, unsigned sbl, cons
     bm &= bm - 1u;
     const unsigned am = T.c_amask[k];
     if ((am >> li) & 1u) {
-      const int p = __popc(am & ((1u << li) - 1u));
-      acc += T.c_J[k][0][p] * w[k][0] + T.c_J[k][1][p] * w[k][1] + T.c_J[k][2][p] * w[k][2];
+      const V3 u = cj_u(T, k, f, c0);
+      acc += cj_row(T, k, 0, u) * w[k][0] + cj_row(T, k, 1, u) * w[k][1] + cj_row(T, k, 2, u) * w[k][2];
     }
   }
   return acc;
@@ -1488,30 +1511,6 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   // ---- contact rows: Jacobians over the chain dofs (jac2 - jac1, geom1 = ball), impedance, reference acceleration
   const M3 Rb = q2m(c.bq);
   DM_SYNC();
-  for (int item = lane; item < nc * NCH; item += 64) {
-    const int k = item / NCH, p = item - k * NCH;
-    float j0 = 0.f, j1 = 0.f, j2 = 0.f;
-    if (p < T.c_nch[k]) {
-      const S6 cd = ld6(T.C[T.c_chain[k][p]]);
-      const V3 r = V3{T.c_pos[k][0], T.c_pos[k][1], T.c_pos[k][2]} - c0;
-      const V3 u = lin(cd) + cross(ang(cd), r);
-      const float *fr = T.c_frame[k];
-      j0 = fr[0] * u.x + fr[1] * u.y + fr[2] * u.z; j1 = fr[3] * u.x + fr[4] * u.y + fr[5] * u.z; j2 = fr[6] * u.x + fr[7] * u.y + fr[8] * u.z;
-    }
-    T.c_J[k][0][p] = j0; T.c_J[k][1][p] = j1; T.c_J[k][2][p] = j2;
-  }
-  if (lane < nc) {
-    const V3 r = V3{T.c_pos[lane][0], T.c_pos[lane][1], T.c_pos[lane][2]} - bc;
-    const float *fr = T.c_frame[lane];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const V3 ek = {k == 0 ? Rb.m0 : (k == 1 ? Rb.m1 : Rb.m2), k == 0 ? Rb.m3 : (k == 1 ? Rb.m4 : Rb.m5), k == 0 ? Rb.m6 : (k == 1 ? Rb.m7 : Rb.m8)};
-      const V3 u = cross(ek, r);
-      T.c_Jb[lane][0][k] = -(fr[0] * u.x + fr[1] * u.y + fr[2] * u.z);
-      T.c_Jb[lane][1][k] = -(fr[3] * u.x + fr[4] * u.y + fr[5] * u.z);
-      T.c_Jb[lane][2][k] = -(fr[6] * u.x + fr[7] * u.y + fr[8] * u.z);
-    }
-  }
   DM_SYNC();
   // per-contact parameters and the adhesion pull (mj: mj_transmission mjTRN_BODY: -force along the normal row).
   // Row-parallel: a row of 16 lanes handles one contact, lane p of the row the p-th dof of its chain.
@@ -1520,11 +1519,12 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     const bool on = k < nc;
     const bool pv = on && p < T.c_nch[k];
     const float vv = pv ? T.V[T.c_chain[k][p]] : 0.f;
+    const V3 uj = pv ? cj_u(T, k, T.c_chain[k][p], c0) : V3{0.f, 0.f, 0.f};
     float vel[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      vel[r] = row_sum(pv ? T.c_J[k][r][p] * vv : 0.f);
-      if (on) vel[r] += T.c_Jb[k][r][0] * c.bw.x + T.c_Jb[k][r][1] * c.bw.y + T.c_Jb[k][r][2] * c.bw.z;
+      vel[r] = row_sum(pv ? cj_row(T, k, r, uj) * vv : 0.f);
+      if (on) { const V3 jb = cj_ball(T, k, r, Rb, bc); vel[r] += jb.x * c.bw.x + jb.y * c.bw.y + jb.z * c.bw.z; }
     }
     if (on && p == 0) {
       const float K = T.c_par[k][0], B = T.c_par[k][1], invw = T.c_par[k][2], incl = T.c_par[k][4], dist = T.c_dist[k];
@@ -1561,14 +1561,15 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       const int a0 = M.s_act[0][s][lane], a1 = M.s_act[1][s][lane];
       if (a0 >= 0) f += M.s_actcoef[0][s][lane] * T.frc[a0];
       if (a1 >= 0) f += M.s_actcoef[1][s][lane] * T.frc[a1];
-      if (nc) f += contact_gather(c, opq(c.sbl[s]), T.c_w);
-      if (nsc) f += self_gather(c, opq(c.sbl[s]), T.c_w);
+      if (nc) f += contact_gather(c, opq(c.sbl[s]), opq(c.sdof[s]), c0, T.c_w);
+      if (nsc) f += self_gather(c, opq(c.sbl[s]), opq(c.sdof[s]), c0, T.c_w);
       qs[s] = f;
     }
   }
   V3 qsb = c.btau;
   for (int k = 0; k < nc; k++) {
-    qsb.x += T.c_Jb[k][0][0] * T.c_w[k][0]; qsb.y += T.c_Jb[k][0][1] * T.c_w[k][0]; qsb.z += T.c_Jb[k][0][2] * T.c_w[k][0];
+    const V3 jb = cj_ball(T, k, 0, Rb, bc);
+    qsb.x += jb.x * T.c_w[k][0]; qsb.y += jb.y * T.c_w[k][0]; qsb.z += jb.z * T.c_w[k][0];
   }
   const float Ib = M.b_I;
   const V3 amb = frcp(Ib) * qsb;
@@ -1633,7 +1634,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   if (lane < nrc) {  // contact rows: the ball's share of J a_s minus aref; the fly's share comes with the first solve
     const int k = lane / 3, r = lane - 3 * k;
     T.r_blk[lane] = (unsigned char)T.c_blk[k];
-    T.r_y0[lane] = T.c_Jb[k][r][0] * amb.x + T.c_Jb[k][r][1] * amb.y + T.c_Jb[k][r][2] * amb.z - T.c_aref[k][r];
+    const V3 jb = cj_ball(T, k, r, Rb, bc);
+    T.r_y0[lane] = jb.x * amb.x + jb.y * amb.y + jb.z * amb.z - T.c_aref[k][r];
   }
   for (int k = lane; k < NBLK * KCOL; k += 64) (&T.rowof[0][0])[k] = 255;
   // warm start from the force this link's contact carried last substep
@@ -1683,7 +1685,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   const int gtri = lane * (lane + 1) / 2;  // G is symmetric: row `lane` keeps its columns r2 <= lane
   {
     V3 ja = {0.f, 0.f, 0.f};  // this row's ball Jacobian (zero for limit rows); the other rows' come by v_readlane
-    if (lane < nrc) { const float *jp = T.c_Jb[lane / 3][lane % 3]; ja = {jp[0] * iIb, jp[1] * iIb, jp[2] * iIb}; }
+    if (lane < nrc) { const V3 jp = cj_ball(T, lane / 3, lane % 3, Rb, bc); ja = {jp.x * iIb, jp.y * iIb, jp.z * iIb}; }
     for (int r2 = 0; r2 < R; r2++) {
       const float gv = (ja.x * rl_f(ja.x, r2) + ja.y * rl_f(ja.y, r2) + ja.z * rl_f(ja.z, r2)) * Ib;
       if (lane < R && r2 <= lane) T.G[gtri + r2] = gv;
@@ -1700,13 +1702,13 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     }
     for (int item = lane; item < nrc * NCH; item += 64) {  // contact rows: J' over the chain
       const int r = item / NCH, p = item - r * NCH, k = r / 3, col = (int)T.r_col[r] + 1 - cb;
-      if (col >= 0 && col < 4 && p < T.c_nch[k]) (&T.X4[T.c_chain[k][p]].x)[col] = T.c_J[k][r - 3 * k][p];
+      if (col >= 0 && col < 4 && p < T.c_nch[k]) { const int f = T.c_chain[k][p]; (&T.X4[f].x)[col] = cj_row(T, k, r - 3 * k, cj_u(T, k, f, c0)); }
     }
     if (lane >= nrc + nsc && lane < R) {
       const int col = (int)T.r_col[lane] + 1 - cb;
       if (col >= 0 && col < 4) (&T.X4[T.r_dof[lane]].x)[col] = T.r_sgn[lane];
     }
-    if (nsc) self_rhs(c.T, lane, nc, nsc, nrc, cb);
+    if (nsc) self_rhs(c.T, lane, nc, nsc, nrc, cb, c0.x, c0.y, c0.z);
     DM_SYNC();
     solve4(c, T.Lm, T.dinv_m);
     if (cb == 0) {
@@ -1718,8 +1720,9 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
       if (lane < nrc) {
         const int k = lane / 3, r = lane - 3 * k, nch = T.c_nch[k];
         for (int p = 0; p < nch; p++) {
-          const float jv = T.c_J[k][r][p];
-          const float4 y = T.X4[T.c_chain[k][p]];
+          const int f = T.c_chain[k][p];
+          const float jv = cj_row(T, k, r, cj_u(T, k, f, c0));
+          const float4 y = T.X4[f];
           acc.x += jv * y.x; acc.y += jv * y.y; acc.z += jv * y.z; acc.w += jv * y.w;
         }
       } else if (lane < nrc + nsc) {  // fly-fly row: self_gacc below
@@ -1740,7 +1743,7 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
         }
       }
     }
-    if (nsc) self_gacc(c.T, lane, nc, nsc, nrc, cb);
+    if (nsc) self_gacc(c.T, lane, nc, nsc, nrc, cb, c0.x, c0.y, c0.z);
     DM_SYNC();
   }
   BSTAMP(8);  // constraint rows + G
@@ -1783,8 +1786,8 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
     qc[s] = 0.f;
     if (slot_on(c, s)) {
       if (lrow[s] >= 0) { const float lf_ = T.r_f[lrow[s]]; qc[s] = lsgn[s] * lf_; c.wsl[s] = lf_; } else c.wsl[s] = 0.f;
-      if (nc) qc[s] += contact_gather(c, opq(c.sbl[s]), T.c_f);
-      if (nsc) qc[s] += self_gather(c, opq(c.sbl[s]), T.c_f);
+      if (nc) qc[s] += contact_gather(c, opq(c.sbl[s]), opq(c.sdof[s]), c0, T.c_f);
+      if (nsc) qc[s] += self_gather(c, opq(c.sbl[s]), opq(c.sdof[s]), c0, T.c_f);
     }
   }
   c.wsc[0] = c.wsc[1] = c.wsc[2] = 0.f;
@@ -1792,9 +1795,10 @@ __device__ __forceinline__ void stage2(Ctx &c, float act_reg, float ctrl_reg, fl
   V3 qcb = {0.f, 0.f, 0.f};
   for (int k = 0; k < nc; k++) {
     const float f0 = T.c_f[k][0], f1 = T.c_f[k][1], f2 = T.c_f[k][2];
-    qcb.x += T.c_Jb[k][0][0] * f0 + T.c_Jb[k][1][0] * f1 + T.c_Jb[k][2][0] * f2;
-    qcb.y += T.c_Jb[k][0][1] * f0 + T.c_Jb[k][1][1] * f1 + T.c_Jb[k][2][1] * f2;
-    qcb.z += T.c_Jb[k][0][2] * f0 + T.c_Jb[k][1][2] * f1 + T.c_Jb[k][2][2] * f2;
+    const V3 b0 = cj_ball(T, k, 0, Rb, bc), b1 = cj_ball(T, k, 1, Rb, bc), b2 = cj_ball(T, k, 2, Rb, bc);
+    qcb.x += b0.x * f0 + b1.x * f1 + b2.x * f2;
+    qcb.y += b0.y * f0 + b1.y * f1 + b2.y * f2;
+    qcb.z += b0.z * f0 + b1.z * f1 + b2.z * f2;
   }
   // final acceleration a = a_s + M^-1 J' f and the Euler acceleration (M + h B)^-1 (qfrc_smooth + J' f) (mj: mj_Euler, implicit in
   // the joint damping) in one pass: component x through M's factor, component y through the factor of M + h B
