@@ -752,7 +752,7 @@ CVX_FN Result cyl_cyl(const Geom &g1, const Geom &g2) {
 }
 
 #ifndef CVX_ELLCYL_ITERS
-#define CVX_ELLCYL_ITERS 12
+#define CVX_ELLCYL_ITERS 8   // (Newton converges in 3 - 5 steps; the cap only bounds the backtracking cases: 8 and 6 pass every bound of tests/test_convex_f32_cpu.py)
 #endif
 // (`n0`: the pair's direction of the last substep, when `have_n`: the ellipsoid classes then refine it instead of searching)
 template <bool WITH_RARE = true>
