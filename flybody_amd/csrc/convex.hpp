@@ -751,8 +751,14 @@ CVX_FN Result cyl_cyl(const Geom &g1, const Geom &g2) {
   return distance<6, 4>(g1, g2, V3{0.f, 0.f, 0.f}, false, 0.05f * fminf(g1.s0, g2.s0), 1e30f);
 }
 
+#ifndef CVX_PRIM_ITERS
+#define CVX_PRIM_ITERS 8
+#endif
+#ifndef CVX_ELLELL_ITERS
+#define CVX_ELLELL_ITERS 8
+#endif
 #ifndef CVX_ELLCYL_ITERS
-#define CVX_ELLCYL_ITERS 8   // (Newton converges in 3 - 5 steps; the cap only bounds the backtracking cases: 8 and 6 pass every bound of tests/test_convex_f32_cpu.py)
+#define CVX_ELLCYL_ITERS 8   // (12 measured the same parity and cost 4 % of the flight throughput: the second collision pass sets the length of the launch; 6 passes the host bounds but loses a cold wing-blade contact: tests/test_gpu_parity.py::test_forced_contacts_one_substep)
 #endif
 // (`n0`: the pair's direction of the last substep, when `have_n`: the ellipsoid classes then refine it instead of searching)
 template <bool WITH_RARE = true>
@@ -761,10 +767,10 @@ CVX_FN Contact collide(const Geom &g1, const Geom &g2, V3 n0 = V3{0.f, 0.f, 0.f}
   out.t = 0.f;
   if (g2.type <= CAPSULE) return capsule_capsule(g1, g2);
   if (g1.type <= CAPSULE) {  // sphere / capsule against ellipsoid / cylinder
-    const PResult r = prim_convex<8>(g1, g2, t0, have_n);
+    const PResult r = prim_convex<CVX_PRIM_ITERS>(g1, g2, t0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos; out.t = r.t;
   } else if (g2.type == ELLIPSOID) {
-    const Result r = ell_ell<8>(g1, g2, n0, have_n);
+    const Result r = ell_ell<CVX_ELLELL_ITERS>(g1, g2, n0, have_n);
     out.dist = r.dist; out.n = r.n; out.pos = r.pos;
   } else if (!WITH_RARE) {  // (two-pass callers: the rare classes are the second pass's)
     out.dist = 1e30f; out.n = V3{1.f, 0.f, 0.f}; out.pos = g1.c;
