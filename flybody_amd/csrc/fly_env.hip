@@ -1069,7 +1069,7 @@ __device__ __forceinline__ float2 bsolve(Ctx &c, float rhs, float rhs_b = 0.f) {
   STAMP(6);
   float x0 = is_dof ? rhs : 0.f, x1 = MODE == 3 ? (is_dof ? rhs_b : 0.f) : x0;
   // ---- x <- L^-T x, branches: step t eliminates the t-th pivot of every branch
-#pragma unroll
+#pragma unroll 1  // (rolled over the four sequence words: 26 KB less code over the kernel's five inlined copies, +0.3 %)
   for (int w = 0; w < 4; w++) {
     const unsigned word = w == 0 ? c.seq0 : (w == 1 ? c.seq1 : (w == 2 ? c.seq2 : c.seq3));
 #pragma unroll
@@ -1124,7 +1124,7 @@ __device__ __forceinline__ float2 bsolve(Ctx &c, float rhs, float rhs_b = 0.f) {
     }
   }
   const int pk = my_end | (dep << 8);
-#pragma unroll
+#pragma unroll 1
   for (int w = 3; w >= 0; w--) {
     const unsigned word = w == 0 ? c.seq0 : (w == 1 ? c.seq1 : (w == 2 ? c.seq2 : c.seq3));
 #pragma unroll
