@@ -467,20 +467,34 @@ __device__ __noinline__ int self_collide(BTile *Tp, ModelPtr Mp, const int lane,
     const unsigned long long bal = __ballot(hit);
     if (bal) {
       const int idx = nc + nsc + __popcll(bal & ((1ull << lane) - 1ull));
-      if (hit && idx < NC) {
+      auto store = [&](int at) {
         const float incl = margin - (margin != 0.f ? M.sc_gap : 0.f);
-        T.c_link[idx] = M.pgs_link[s1] | (M.pgs_link[s2] << 8);
-        T.c_pid[idx] = (unsigned short)(0x8000 | s1 | (s2 << 6));
-        T.c_excl[idx] = dist >= incl ? 1 : 0;
-        T.c_dist[idx] = dist;
-        T.c_pos[idx][0] = cpos.x; T.c_pos[idx][1] = cpos.y; T.c_pos[idx][2] = cpos.z;
-        T.c_frame[idx][0] = nrm.x; T.c_frame[idx][1] = nrm.y; T.c_frame[idx][2] = nrm.z;
-        T.c_par[idx][0] = M.sc_K; T.c_par[idx][1] = M.sc_B; T.c_par[idx][2] = M.pgs_invw[s1] + M.pgs_invw[s2]; T.c_par[idx][3] = 0.f;
-        T.c_par[idx][4] = incl;
-      }
+        T.c_link[at] = M.pgs_link[s1] | (M.pgs_link[s2] << 8);
+        T.c_pid[at] = (unsigned short)(0x8000 | s1 | (s2 << 6));
+        T.c_excl[at] = dist >= incl ? 1 : 0;
+        T.c_dist[at] = dist;
+        T.c_pos[at][0] = cpos.x; T.c_pos[at][1] = cpos.y; T.c_pos[at][2] = cpos.z;
+        T.c_frame[at][0] = nrm.x; T.c_frame[at][1] = nrm.y; T.c_frame[at][2] = nrm.z;
+        T.c_par[at][0] = M.sc_K; T.c_par[at][1] = M.sc_B; T.c_par[at][2] = M.pgs_invw[s1] + M.pgs_invw[s2]; T.c_par[at][3] = 0.f;
+        T.c_par[at][4] = incl;
+      };
+      if (hit && idx < NC) store(idx);
       const int n = __popcll(bal);
-      if (nc + nsc + n > NC) ovf = 1;  // more contacts than the tile holds: the extra ones are dropped and the env is flagged
+      const bool over = nc + nsc + n > NC;
       nsc = min(nsc + n, NC - nc);
+      if (over && nc < NC) {
+        // More contacts than the tile holds: the env is flagged, and a hit without a slot takes the place of the shallowest fly-fly
+        // contact held so far if it is deeper (as for the ball contacts and the convex pairs: a deep contact is never the one dropped).
+        ovf = 1;
+        DM_SYNC();
+        for (unsigned long long left = __ballot(hit && idx >= NC); left; left &= left - 1) {
+          const int j = __ffsll((long long)left) - 1;
+          float shallow = -1e30f;
+          int at = -1;
+          for (int k = nc; k < NC; k++) { const float dk = T.c_dist[k]; if (dk > shallow) { shallow = dk; at = k; } }
+          if (__shfl(dist, j) < shallow) { if (lane == j) store(at); DM_SYNC(); }
+        }
+      } else if (over) ovf = 1;
     }
   }
   return nsc | (ovf << 8) | (ndrop << 16);

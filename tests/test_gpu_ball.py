@@ -127,6 +127,34 @@ def test_one_substep_at_saturated_actions(torch_mod):
     assert eq < 1e-6 and ev < 1.5e-4  # measured 2.2e-7 / 4.6e-5
 
 
+def test_forced_capacity_overflow_stays_finite(torch_mod):
+    """poses no policy reaches - every hinge drawn uniformly over its range, legs, wings and abdomen through each other - put far
+    more geom pairs in contact than the tile's 16 slots.  The kernel flags those envs (task-state int 7, bit 0), keeps the deepest
+    contacts (ball contacts, sphere / capsule pairs and convex pairs alike) and must stay finite through a whole control step."""
+    from flybody_amd.model.blob import read_blob
+
+    t = read_blob(BALL_BLOB)
+    rng = np.random.RandomState(17)
+    lo, hi = np.asarray(t["jnt_range"])[:, 0], np.asarray(t["jnt_range"])[:, 1]
+    adr = np.asarray(t["jnt_qposadr"])
+    hinge = [j for j in range(len(adr)) if int(t["jnt_type"][j]) == 3]
+    m, base = _oracle_states(1, 0.2, seed=3)
+    states = []
+    for _ in range(48):
+        q = base[0][0].copy()
+        for j in hinge:
+            if hi[j] > lo[j]:
+                q[int(adr[j])] = rng.uniform(lo[j], hi[j])
+        states.append((q, np.zeros_like(base[0][1]), base[0][2].copy()))
+    ctrls = [rng.uniform(-1.0, 1.0, 59).astype(np.float32) for _ in states]
+    q, v, a, ints = _gpu_advance(torch_mod, states, ctrls, 10)
+    flagged = int((ints[:, 7] & 1).sum())
+    print(f"forced overflow: {flagged} of {len(states)} envs flagged 'more than 16 contacts', contacts at the end of the step max {int(ints[:, 5].max())}")
+    assert flagged >= 4, ints[:, 7].tolist()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(a).all()
+    assert np.abs(v).max() < 1e6
+
+
 def test_ten_substeps_open_loop(torch_mod):
     m, states = _oracle_states(16, 0.4, seed=7)
     rs = np.random.RandomState(3)
