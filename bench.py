@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-async-groups", action="store_true", help="skip the extra measurement of the same envs as two asynchronous groups")
     ap.add_argument("--action-amplitude", type=float, default=0.2,
                     help="walk_on_ball: raw actions U(-a, a)^59; 0.2 = BASELINE configs[2] (task_utils.py:13-24), 1.0 = every actuator saturating")
     ap.add_argument("--rehearse-gather", action="store_true",
@@ -311,6 +312,35 @@ def main():
     sync()
     k_ms_region = ev0.elapsed_time(ev1) / args.steps if ev0 is not None else k_ms
 
+    # What an asynchronous consumer gets from the same envs on this GPU (reported beside the headline, never as `value`): the batch as two
+    # groups of B / 2 envs, each stepped on its own HIP stream, ordered only against its own previous step - the reference's actors are
+    # separate processes that never wait for each other.  One group's drain overlaps the other's start.
+    async_groups = None
+    if world == 1 and not fake and not args.no_async_groups and B % 2 == 0:
+        from flybody_amd.groups import EnvGroups
+
+        fence()
+        G = 2
+        if ball:
+            grp = EnvGroups(fly_envs.walk_on_ball, B, groups=G, device=local_rank)
+        else:
+            grp = EnvGroups(fly_envs.flight_imitation, B, groups=G, device=local_rank, random_state=0, env_id_base=env_id_base)
+        gacts = [[acts[k][grp.rows(gi)].contiguous() for k in range(npool)] for gi in range(G)]
+        grp.reset()
+        sync()
+        for k in range(args.warmup + args.steps):  # (as deep into the episodes as the headline region started its last step)
+            grp.step([gacts[gi][k % npool] for gi in range(G)])
+        grp.synchronize(); sync()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            grp.step([gacts[gi][k % npool] for gi in range(G)])
+        grp.synchronize(); sync()
+        el = time.perf_counter() - t1
+        async_groups = {"groups": G, "envs_per_group": B // G, "value": round(B * args.steps / el, 1), "unit": "env-steps/s", "ms_per_step_of_all_envs": round(1e3 * el / args.steps, 4),
+                        "note": "same envs, same actions, same results (tests/test_gpu_groups.py); needs a consumer that works per group on the group's stream (flybody_amd/groups.py)"}
+        grp.close()
+
+
     if rank == 0:
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate
         # FETCH_SIZE / WRITE_SIZE runs; KiB units; read side doubled per the gfx950 note in MI355X_MICROARCH.md - an
@@ -368,6 +398,8 @@ def main():
             flagged = int((ints[:, 7] != 0).sum()) if ball else int((((ints[:, 7] >> 8) & 255) != 0).sum())
             out["capacity"] = {"envs_flagged_at_end": flagged, "of": B,
                                "limits": "16 contacts / 48 constraint rows / 24 columns per block of M" if ball else "6 simultaneous contacts of the fly with itself"}
+        if async_groups is not None:
+            out["async_groups"] = async_groups
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if rehearsal is not None:

@@ -145,10 +145,7 @@ class BatchedActorLoop:
         it matters for small batches).  Needs a policy whose work is all on the
         env's device and free of host synchronisation; the env must not be double-buffered."""
         t = self._t
-        ts = self.env.reset()
-        self._ret.zero_(); self._len.zero_(); self._tot.zero_(); self._sum_ret.zero_()
-        if self.adder is not None:
-            self.adder.observe(t.zeros(self.env.batch_size, self.adder.act_dim, device=self.env.device), ts, self.env.flat_observation)
+        self._begin()
         if graph:
             side = t.cuda.Stream(self.env.device)
             side.wait_stream(t.cuda.current_stream(self.env.device))
@@ -179,6 +176,14 @@ class BatchedActorLoop:
                 "episode_length": float(self._tot[1].item()) / n if n else float("nan"),
                 "steps_per_second": num_steps * self.env.batch_size / wall, "capacity_flagged_envs": self._flagged()}
 
+    def _begin(self):
+        """reset + `observe_first`, statistics zeroed (on torch's current stream)"""
+        t = self._t
+        ts = self.env.reset()
+        self._ret.zero_(); self._len.zero_(); self._tot.zero_(); self._sum_ret.zero_()
+        if self.adder is not None:
+            self.adder.observe(t.zeros(self.env.batch_size, self.adder.act_dim, device=self.env.device), ts, self.env.flat_observation)
+
     def _flagged(self) -> int:
         """Envs whose step met more simultaneous contacts / constraint rows than the kernel carries (`ffe_get_task_state` int 7: the
         deepest contacts are kept, the env is flagged - walk_on_ball: sticky over the episode; flight: the last control step)."""
@@ -187,3 +192,53 @@ class BatchedActorLoop:
         w = self.env.get_task_state()[0][:, 7]
         is_flight = hasattr(self.env, "ghost_accel_z")
         return int((((w >> 8) & 255) != 0).sum()) if is_flight else int((w != 0).sum())
+
+
+
+class GroupedActorLoop:
+    """The actor loop over asynchronous env groups (`flybody_amd.groups.EnvGroups`): one `BatchedActorLoop` per group, everything a group
+    does - policy, env step, adder, statistics - on that group's stream, the host enqueueing the groups round-robin.  No group waits for
+    another, as the reference's actor processes do not (`train_dmpo_ray.py:432-452`); one group's launch drains while the next group's
+    fills the device.  The policy is shared (its weights are read-only here)."""
+
+    def __init__(self, groups, policy, adders=None):
+        self.groups = groups
+        self.loops = [BatchedActorLoop(e, policy, adders[g] if adders is not None else None) for g, e in enumerate(groups.envs)]
+
+    def run(self, num_steps: int, graph: bool = False) -> dict:
+        """`graph`: every group's iteration is captured once into a HIP graph on the group's stream and replayed (two dozen launches per
+        group and step otherwise: with several groups the host becomes the bound before the device does)."""
+        import torch
+
+        for g, lp in enumerate(self.loops):
+            with self.groups.on(g):
+                lp._begin()
+        self.groups.synchronize()
+        graphs = None
+        if graph:
+            graphs = []
+            for g, lp in enumerate(self.loops):
+                with self.groups.on(g):
+                    for _ in range(3):
+                        lp._iteration()
+                self.groups.streams[g].synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=self.groups.streams[g]):
+                    lp._iteration()
+                graphs.append(gr)
+            self.groups.synchronize()
+        start = time.perf_counter()
+        for _ in range(num_steps):
+            for g, lp in enumerate(self.loops):
+                with self.groups.on(g):
+                    if graphs is not None:
+                        graphs[g].replay()
+                    else:
+                        lp._iteration()
+        self.groups.synchronize()
+        wall = time.perf_counter() - start
+        n = sum(int(lp._tot[0].item()) for lp in self.loops)
+        ret = sum(float(lp._sum_ret.item()) for lp in self.loops)
+        length = sum(int(lp._tot[1].item()) for lp in self.loops)
+        return {"episodes": n, "episode_return": ret / n if n else float("nan"), "episode_length": length / n if n else float("nan"),
+                "steps_per_second": num_steps * self.groups.batch_size / wall, "capacity_flagged_envs": sum(lp._flagged() for lp in self.loops)}

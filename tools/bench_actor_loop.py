@@ -56,4 +56,24 @@ for name in ("env_only_fixed_action", "env_plus_policy", "env_plus_policy_plus_n
     if adder is not None:
         out[name]["transitions_written"] = adder.num_written(); adder.close()
     env.close()
+# the same actor as two asynchronous groups of B / 2 envs (flybody_amd/groups.py, GroupedActorLoop): policy, env step and writer of a group
+# on that group's stream, nobody waits for the other group
+from flybody_amd import fly_envs
+from flybody_amd.actor_loop import GroupedActorLoop
+from flybody_amd.groups import EnvGroups
+
+for G in (2,):
+    grp = EnvGroups(fly_envs.flight_imitation, B, groups=G, random_state=0, canonical_actions=True, clip_actions=True)
+    pol = Policy(grp.envs[0].spec.obs_dim, grp.envs[0].spec.action_dim).cuda()
+    adders = [NStepTransitionWriter(B // G, e.spec.obs_dim, e.spec.action_dim, n_step=50, discount=0.99, capacity=1 << 19) for e in grp.envs]
+    loop = GroupedActorLoop(grp, pol, adders)
+    loop.run(30)
+    r = loop.run(steps)
+    out[f"env_plus_policy_plus_nstep_writer_{G}_async_groups"] = {"env_steps_per_s": round(r["steps_per_second"], 1), "ms_per_step": round(1e3 * B / r["steps_per_second"], 4),
+                                                                "episodes": r["episodes"], "mean_episode_length": round(r["episode_length"], 1),
+                                                                "transitions_written": sum(a.num_written() for a in adders)}
+    rg = loop.run(steps, graph=True)
+    out[f"env_plus_policy_plus_nstep_writer_{G}_async_groups"]["hip_graph"] = {"env_steps_per_s": round(rg["steps_per_second"], 1), "ms_per_step": round(1e3 * B / rg["steps_per_second"], 4), "episodes": rg["episodes"]}
+    for a in adders: a.close()
+    grp.close()
 print(json.dumps(out))
