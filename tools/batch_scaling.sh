@@ -5,7 +5,7 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for b in 2048 4096 8192 16384 32768; do
-  timeout -k 10 200 python bench.py --no-cpu-baseline --envs-per-gpu $b --steps 200 --warmup 30 2>/dev/null | tail -1 | python -c "
+  timeout -k 10 200 python bench.py --no-cpu-baseline --no-async-groups --envs-per-gpu $b --steps 200 --warmup 30 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print(json.dumps({'workload': 'flight_imitation', 'envs': d['config']['envs_per_gpu'], 'ms_per_step': d['ms_per_step'], 'env_steps_per_s': d['value']}))" || exit 1
 done

@@ -13,7 +13,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM
            "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQC_TC_INST_REQ" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pass$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pass$i -o p -- python3 $R/bench.py --no-cpu-baseline --no-async-groups --steps 10 --warmup 3 > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, json, statistics
@@ -27,7 +27,7 @@ for f in glob.glob("$OUT/pass*/*counter_collection.csv"):
     for k, v in vals.items():
         v = v[2:] if len(v) > 4 else v  # drop the reset launch and the first steps
         out[k] = {"median": statistics.median(v), "min": min(v), "max": max(v), "n": len(v)}
-out["_command"] = "rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 (one run per group); per-launch values of flight_step_kernel at B=8192"
+out["_command"] = "rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py --no-cpu-baseline --no-async-groups --steps 10 --warmup 3 (one run per group); per-launch values of flight_step_kernel at B=8192"
 json.dump(out, open("$R/gpurun_out/r03_pmc_flight_kernel.json", "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict): print(k, v["median"])

@@ -5,7 +5,7 @@ OUT=$R/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $OUT/$c.log 2>&1 || { echo "$c failed"; tail -3 $OUT/$c.log; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python3 $R/bench.py --no-cpu-baseline --no-async-groups --steps 10 --warmup 3 > $OUT/$c.log 2>&1 || { echo "$c failed"; tail -3 $OUT/$c.log; }
 done
 python3 - <<PY
 import csv, glob, statistics
