@@ -167,8 +167,12 @@ def main():
 
     global BALL_AMP
     BALL_AMP = float(args.action_amplitude)
+    # FLYBODY_BENCH_FORCE_MULTI=1 (rehearsal on one GPU): take the N > 1 path - process group, action scatter, timestep gather as real RCCL
+    # collectives on a one-rank group, double buffering, barriers - with the real env.  Everything but the wire.
+    multi = world > 1 or os.environ.get("FLYBODY_BENCH_FORCE_MULTI") == "1"
+    forced = multi and world == 1
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(workload=args.workload)  # before any GPU initialisation (uses fork)
 
     import torch
@@ -182,8 +186,10 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         backend = "nccl"
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced:
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, **({} if fake else {"device_id": dev}))
 
     from flybody_amd.distributed import ActionScatter, TimestepGather, shard
@@ -210,9 +216,9 @@ def main():
     # all N * B envs and every rank receives its block through one scatter per step, issued one step ahead (double-buffered) so that
     # it travels while the current step is simulated
     nact = spec.shape[0]
-    rows = B * world if (world > 1 and rank == 0) else B
-    acts = [(lo + (hi - lo) * torch.rand(rows, nact, device=dev, generator=g)).contiguous() for _ in range(npool)] if (world == 1 or rank == 0) else None
-    scatters = [ActionScatter(B, nact, dev, world, rank) for _ in range(2)] if world > 1 else None
+    rows = B * world if (multi and rank == 0) else B
+    acts = [(lo + (hi - lo) * torch.rand(rows, nact, device=dev, generator=g)).contiguous() for _ in range(npool)] if (not multi or rank == 0) else None
+    scatters = [ActionScatter(B, nact, dev, world, rank, force_collective=forced) for _ in range(2)] if multi else None
     swork = [None, None]
 
     def issue_scatter(k):
@@ -220,11 +226,11 @@ def main():
 
     # The per-step gather of everything a central learner consumes: one RCCL call per step,
     # double-buffered so that the gather of step k travels over xGMI while step k+1 is being simulated.
-    gathers = [TimestepGather(B, env.spec.obs_dim, dev, world, rank) for _ in range(2)]
+    gathers = [TimestepGather(B, env.spec.obs_dim, dev, world, rank, force_collective=forced) for _ in range(2)]
     works = [None, None]
 
     def one_step(k):
-        if world > 1:
+        if multi:
             if swork[k & 1] is None:
                 issue_scatter(k)
             swork[k & 1].wait()
@@ -234,7 +240,7 @@ def main():
         else:
             a = acts[k % npool]
         ts = env.step(a)
-        if world > 1:
+        if multi:
             i = k & 1
             if works[i] is not None:
                 works[i].wait()
@@ -261,7 +267,7 @@ def main():
     def fence():
         drain()
         sync()
-        if world > 1:
+        if multi:
             dist.barrier()
         sync()
 
@@ -280,13 +286,13 @@ def main():
         ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     rehearsal = None
-    if args.rehearse_gather and world == 1 and not fake:
+    if args.rehearse_gather and not multi and not fake:
         # the N>1 step = env.step + pack into one [B, O + 3] buffer + one RCCL gather; at N=1 only the collective is missing
         fence()
         t1 = time.perf_counter()
@@ -307,7 +313,7 @@ def main():
     # kernel trace reports for it); the timed region's own events also span the 6-12 us launch-order kernel that follows every step
     # (one launch per call, cycling through the same action pool as the timed region: same workload)
     nk = min(args.steps, 100)
-    kacts = [acts[k % npool] for k in range(nk)] if world == 1 else [scatters[0].local] * nk  # (N > 1: the block last received)
+    kacts = [acts[k % npool] for k in range(nk)] if not multi else [scatters[0].local] * nk  # (N > 1: the block last received)
     k_ms = (sum(env.time_kernel(kacts[k], 1) for k in range(nk)) / nk) if hasattr(env, "time_kernel") else env.time_steps(kacts[0], nk)
     sync()
     k_ms_region = ev0.elapsed_time(ev1) / args.steps if ev0 is not None else k_ms
@@ -316,7 +322,7 @@ def main():
     # groups of B / 2 envs, each stepped on its own HIP stream, ordered only against its own previous step - the reference's actors are
     # separate processes that never wait for each other.  One group's drain overlaps the other's start.
     async_groups = None
-    if world == 1 and not fake and not args.no_async_groups and B % 2 == 0:
+    if not multi and not fake and not args.no_async_groups and B % 2 == 0:
         from flybody_amd.groups import EnvGroups
 
         fence()
@@ -382,7 +388,7 @@ def main():
             "config": {"workload": ("walk_on_ball (BASELINE configs[2]): 10 substeps @2e-4 s, ball contacts (elliptic cones, Newton + noslip), the fly's own contacts (every geom pair MuJoCo collides: capsules, ellipsoids, cylinders), adhesion, "
                                     "filtered actuators, touch/force sensors, obs/reward/termination/auto-reset") if ball else
                                    "flight_imitation (BASELINE configs[3]): 4 substeps @5e-5 s (joint limits, fluid forces, the fly's own contacts) + WBPG + obs/reward/termination/auto-reset",
-                       "envs_per_gpu": B, "global_batch": world * B, "parallelism": f"env-sharded x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                       "envs_per_gpu": B, "global_batch": world * B, "parallelism": f"env-sharded x{world}" + (" + RCCL action scatter from / timestep gather to rank 0" if multi else "") + (" (one-rank rehearsal: FLYBODY_BENCH_FORCE_MULTI)" if forced else ""),
                        "actions": f"raw U(-{BALL_AMP:g}, {BALL_AMP:g})^59, resident in HBM" if ball else "uniform over the raw action spec (canonical U(-1,1)), resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
@@ -405,7 +411,7 @@ def main():
         if rehearsal is not None:
             out["gather_rehearsal"] = rehearsal
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

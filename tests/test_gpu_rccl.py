@@ -67,3 +67,26 @@ def test_rccl_gather_and_scatter_at_world_size_1():
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=550)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "RCCL_OK 38" in out.stdout, out.stdout[-500:]
+
+
+@pytest.mark.timeout(600)
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py's N > 1 loop - process group on RCCL, double-buffered action scatter and timestep gather as real collectives, barriers,
+    max-over-ranks timing - with the real env on a one-rank group (FLYBODY_BENCH_FORCE_MULTI): everything but the wire."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, FLYBODY_BENCH_FORCE_MULTI="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "40", "--warmup", "10", "--envs-per-gpu", "2048"],
+                         env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 2048 and "rehearsal" in d["config"]["parallelism"] and d["value"] > 1e6
